@@ -1,0 +1,207 @@
+/*
+ * rhj.h — C-ABI of the MI355X-native radix hash join / filter scan.
+ *
+ * This is the drop-in boundary for ONE hot path of VagelisN/Sigmod-2018:
+ * RadixHashJoin() (rhjoin.c + preprocess.c) and Filter() (filter.c), with the
+ * result-list layout of results.c.  Everything here is plain C: pointers and
+ * sizes, no torch / HIP types in any signature.
+ *
+ * Layout compatibility (all sizes checked by static asserts in rhj_abi.c):
+ *   rhj_tuple        == reference `tuple`          structs.h:15-19   16 B
+ *   rhj_relation     == reference `relation`       structs.h:25-29   16 B
+ *   rhj_result       == reference `result`         structs.h:37-43   24 B
+ *   rhj_result_tuple == reference `result_tuple`   structs.h:46-50   16 B
+ *   rhj_inter_data / rhj_inter_res == `inter_data` / `inter_res`   structs.h:97-111
+ *   rhj_column_stats / rhj_relation_map == `column_stats` / `relation_map` structs.h:120-138
+ *   rhj_filter_pred  == reference `filter_pred`    structs.h:141-147 16 B
+ *
+ * When RHJ_REFERENCE_NAMES is defined before including this header the
+ * reference's own type names are typedef'd onto these, so a translation unit
+ * of the reference's caller side (query.c, inter_res.c) can be compiled
+ * against this header instead of structs.h for the types on this path.
+ */
+#ifndef RHJ_H
+#define RHJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference-compatible data layout ---------------------------------- */
+
+typedef struct rhj_tuple {          /* structs.h:15-19 */
+    uint64_t value;
+    uint64_t row_id;
+} rhj_tuple;
+
+typedef struct rhj_relation {       /* structs.h:25-29 */
+    rhj_tuple *tuples;
+    uint64_t   num_tuples;
+} rhj_relation;
+
+typedef struct rhj_result {         /* structs.h:37-43 */
+    char              *buff;         /* current_load elements, malloc'd   */
+    struct rhj_result *next;
+    uint64_t           current_load; /* elements in buff                  */
+} rhj_result;
+
+typedef struct rhj_result_tuple {   /* structs.h:46-50 */
+    uint64_t row_idR;
+    uint64_t row_idS;
+} rhj_result_tuple;
+
+typedef struct rhj_inter_data {     /* structs.h:97-101 */
+    uint64_t   num_tuples;
+    uint64_t **table;                /* table[rel] == NULL: rel inactive  */
+} rhj_inter_data;
+
+typedef struct rhj_inter_res {      /* structs.h:106-111 */
+    rhj_inter_data       *data;
+    int                   num_of_relations;
+    struct rhj_inter_res *next;
+} rhj_inter_res;
+
+typedef struct rhj_column_stats {   /* structs.h:120-126 */
+    uint64_t l, u;
+    double   f, d;
+} rhj_column_stats;
+
+typedef struct rhj_relation_map {   /* structs.h:132-138 */
+    uint64_t          num_tuples;
+    uint64_t          num_columns;
+    uint64_t        **columns;       /* column-major u64, relation_map.c:39-50 */
+    rhj_column_stats *col_stats;
+} rhj_relation_map;
+
+typedef struct rhj_filter_pred {    /* structs.h:141-147 */
+    int  relation;
+    int  column;
+    int  value;                      /* atoi() of the constant, query.c:239,247 */
+    char comperator;                 /* '<' '>' '='  (spelling is the reference's) */
+} rhj_filter_pred;
+
+/* The reference's scheduler (structs.h:209-222) is opaque here: the GPU path
+ * owns its own parallelism and tolerates sched == NULL (handler.c:60-63 passes
+ * NULL when built with THREADS == 1). */
+struct scheduler;
+
+/* ---- the two boundary functions (names and signatures are the reference's) */
+
+/* rhjoin.h:9, defined rhjoin.c:13-111.  NULL when either input is empty
+ * (rhjoin.c:15-16).  Result order is the canonical order of SURVEY.md A.1:
+ * bucket ascending, probe-side tuple in input order, build-side matches in
+ * descending input position.  Zero matches: see rhj_set_empty_mode(). */
+rhj_result *RadixHashJoin(rhj_relation *relR, rhj_relation *relS,
+                          struct scheduler *sched);
+
+/* filter.h:9, defined filter.c:92-190.  Ascending list of u64 indices i with
+ * col[i] OP (uint64_t)(int)value; through head->data->table[rel][i] when the
+ * relation is already active in the intermediate result.  NULL on zero hits.
+ * An unknown comparator prints the reference's message and exit(2)s
+ * (filter.c:184-186). */
+rhj_result *Filter(rhj_inter_res *head, rhj_filter_pred *filter_p,
+                   rhj_relation_map *map, int *query_relations);
+
+/* ---- result-list API (results.h:7-25), same names, same behaviour -------- */
+rhj_result       *InsertResult(rhj_result **head, rhj_result_tuple *res_tuple);  /* results.c:8-46    */
+rhj_result       *InsertRowIdResult(rhj_result **head, uint64_t *row_id);        /* results.c:155-192 */
+int               GetResultNum(rhj_result *res);                                 /* results.c:65-76   */
+uint64_t          FindResultRowId(rhj_result *res, int num);                     /* results.c:48-64   */
+rhj_result_tuple *FindResultTuples(rhj_result *head, int num);                   /* results.c:126-142 */
+void              FreeResult(rhj_result *head);                                  /* results.c:144-153 */
+void              PrintResult(rhj_result *head);                                 /* results.c:78-100  */
+void              FreeRelation(rhj_relation *rel);                               /* preprocess.c:213-218 */
+/* handler.c:62,102 call these; the GPU path needs no worker threads, so they
+ * allocate/free an inert token (scheduler.c:9-25, :88-107). */
+int               SchedulerInit(struct scheduler **sched, int num_of_threads);
+int               SchedulerDestroy(struct scheduler *sched);
+
+/* ---- knobs the reference hard-codes in structs.h:8-12 -------------------- */
+
+/* N_LSB (structs.h:11), 1..12 here; default 4 or env RHJ_RADIX_BITS.  Returns 0
+ * or -1 on a value outside the supported range. */
+int  rhj_set_radix_bits(int bits);
+int  rhj_get_radix_bits(void);
+/* Zero-match convention (SURVEY.md finding 5): 0 = non-NULL empty head (as
+ * shipped, THREADS 4: rhjoin.c:356-359), 1 = NULL (THREADS 1).  Env RHJ_EMPTY. */
+void rhj_set_empty_mode(int null_on_empty);
+/* Pairs per host result node; default 65535 (MergeResults' strict '<' at
+ * rhjoin.c:371 caps a 1 MiB node at 65535 pairs).  0 = one node for all. */
+void rhj_set_node_pairs(uint64_t pairs_per_node);
+/* Device ordinal (default 0 or env RHJ_DEVICE); must precede the first call. */
+int  rhj_set_device(int ordinal);
+/* Launch all work on this hipStream_t (passed as void*); NULL = own stream. */
+void rhj_set_stream(void *hip_stream);
+/* Force the HBM-table probe path even for buckets whose table fits LDS. */
+void rhj_set_force_hbm_table(int on);
+
+/* ---- device-resident entry points (what RadixHashJoin()/Filter() call
+ *      after staging; bench.py and the parity tests call them directly) ----- */
+
+typedef struct rhj_stats {
+    /* per-stage GPU time of the LAST call in milliseconds (hipEvent pairs on
+     * the launch stream) and the launch counts behind them */
+    float ms_hist, ms_scan, ms_scatter, ms_plan, ms_build, ms_count, ms_offsets,
+          ms_probe, ms_total;
+    float ms_h2d, ms_d2h;
+    uint64_t n_r, n_s, matches;
+    uint64_t units, hbm_units, max_build, table_slots;
+    int radix_bits;
+    int reserved;
+} rhj_stats;
+
+/* Join two device-resident AoS relations (rhj_tuple[nR], rhj_tuple[nS]).
+ * d_out receives up to out_capacity rhj_result_tuple in canonical order.
+ * *matches gets the exact match count even when it exceeds out_capacity (then
+ * nothing beyond capacity is written and the return value is 1).  Returns 0 on
+ * success, <0 on a HIP error (message on stderr). d_out may be NULL with
+ * capacity 0 to count only. */
+int rhj_join_device(const rhj_tuple *d_R, uint64_t nR,
+                    const rhj_tuple *d_S, uint64_t nS,
+                    rhj_result_tuple *d_out, uint64_t out_capacity,
+                    uint64_t *matches);
+
+/* The stable radix partition alone (SerialReorderArray, preprocess.c:302-362):
+ * d_out[n] partitioned tuples, h_hist[2^bits] counts, h_psum[2^bits] starts
+ * (-1 for an empty bucket as preprocess.c:336-347 leaves it).  Host arrays may
+ * be NULL. */
+int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out,
+                         uint64_t *h_hist, int64_t *h_psum);
+
+/* Filter scan on a device-resident column.  d_sel == NULL: scan col[0..n);
+ * else scan col[d_sel[i]] for i in [0,n).  d_out gets the ascending indices i
+ * (capacity n).  op is '<', '>' or '='; value is already converted as the
+ * reference does ((uint64_t)(int)value, filter.c:116).  */
+int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n,
+                      char op, uint64_t value, uint64_t *d_out, uint64_t *hits);
+
+/* Pin a host column store and keep a device copy (relation_map.c:39-50 layout:
+ * the columns of one relation are contiguous, column-major).  Filter() uploads
+ * lazily on first use when this was not called.  rhj_release() drops every
+ * cached device buffer and the workspace. */
+int  rhj_register_relation_map(const rhj_relation_map *map, int num_relations);
+void rhj_release(void);
+
+const rhj_stats *rhj_last_stats(void);
+const char      *rhj_version(void);
+
+#ifdef RHJ_REFERENCE_NAMES
+typedef rhj_tuple        tuple;
+typedef rhj_relation     relation;
+typedef rhj_result       result;
+typedef rhj_result_tuple result_tuple;
+typedef rhj_inter_data   inter_data;
+typedef rhj_inter_res    inter_res;
+typedef rhj_column_stats column_stats;
+typedef rhj_relation_map relation_map;
+typedef rhj_filter_pred  filter_pred;
+typedef struct scheduler scheduler;
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RHJ_H */
