@@ -1,0 +1,516 @@
+// rhj_device.hip — launch orchestration, device workspace and staging behind the
+// C-ABI of include/rhj.h.  The host-facing reference signatures (RadixHashJoin,
+// Filter, result lists) live in rhj_abi.c and call the rhj_host_* helpers below.
+//
+// There is no CPU fallback: any HIP failure is reported on stderr and returned as
+// an error; a missing GPU makes every entry point fail.
+#include "rhj_kernels.hip.h"
+#include "rhj_internal.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <utility>
+
+using namespace rhj;
+
+#define HIP_TRY(x)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) {                                                             \
+            fprintf(stderr, "rhj: %s -> %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                              \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+namespace {
+
+struct Buf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+constexpr int MAX_BITS = 12;
+constexpr uint32_t LDS_BUDGET = 160 * 1024;       // bytes per workgroup on gfx950
+constexpr uint32_t LDS_RESERVED = 512;            // scan scratch behind the table
+
+enum Stage { ST_HIST, ST_SCAN, ST_SCATTER, ST_PLAN, ST_BUILD, ST_COUNT, ST_OFFSETS, ST_PROBE, ST_END, ST_N };
+
+struct Ctx {
+    bool        ready = false;
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = false;
+    int         bits = 4;
+    int         null_on_empty = 0;
+    int         force_hbm = 0;
+    uint64_t    node_pairs = 65535;
+    hipEvent_t  ev[ST_N + 1] = {};
+    hipEvent_t  ev_x[4] = {};
+    Buf partR, partS, cntR, cntS, chunk, histpsum, units, bunits, meta, summary, ucount, ubase, tables;
+    Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
+    void *pin = nullptr;            // small pinned block for read-backs
+    std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
+    rhj_stats stats = {};
+};
+
+Ctx g;
+
+// environment defaults are read once at load time; the rhj_set_* calls override them
+struct EnvDefaults {
+    EnvDefaults()
+    {
+        const char *e;
+        if ((e = getenv("RHJ_DEVICE"))) g.device = atoi(e);
+        if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 12) g.bits = b; }
+        if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
+        if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
+        if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
+    }
+} env_defaults;
+
+int ensure(Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+int ctx_init()
+{
+    if (g.ready) return 0;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) { fprintf(stderr, "rhj: no HIP device visible; this library has no CPU path\n"); return -1; }
+    HIP_TRY(hipSetDevice(g.device));
+    if (!g.stream) { HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true; }
+    for (auto &ev : g.ev) HIP_TRY(hipEventCreate(&ev));
+    for (auto &ev : g.ev_x) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
+    // dynamic LDS above 64 KiB has to be requested per kernel
+    const int big = LDS_BUDGET;
+    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    g.ready = true;
+    return 0;
+}
+
+void tile_geometry(uint64_t n, int bits, uint32_t *tile_len, uint32_t *tiles)
+{
+    // one wave per tile; at 12 bits the 16 KiB of LDS counters admit 10 waves per CU
+    const uint64_t max_tiles = bits >= 11 ? 2560 : 4096;
+    uint64_t t = (n + 2047) / 2048;
+    if (t < 1) t = 1;
+    if (t > max_tiles) t = max_tiles;
+    uint64_t len = (n + t - 1) / t;
+    len = (len + 63) / 64 * 64;
+    if (len == 0) len = 64;
+    *tile_len = (uint32_t)len;
+    *tiles = (uint32_t)((n + len - 1) / len);
+    if (*tiles == 0) *tiles = 1;
+}
+
+struct PartState {
+    RelArgs  r[2];
+    uint64_t *hist, *psum;   // [2][bins] each
+    uint32_t chunks;
+};
+
+// hist + scan + scatter for one or two relations (r[1].n == 0 and tiles == 0 to skip)
+int run_partition(PartState &ps, int bits, int nrel)
+{
+    const uint32_t bins = 1u << bits;
+    const size_t lds = (size_t)bins * 4;
+    uint32_t max_tiles = 0;
+    for (int i = 0; i < nrel; ++i) max_tiles = ps.r[i].tiles > max_tiles ? ps.r[i].tiles : max_tiles;
+    ps.chunks = max_tiles >= 64 ? 32 : 1;
+    if (ensure(g.chunk, (size_t)2 * ps.chunks * bins * 8)) return -1;
+    if (ensure(g.histpsum, (size_t)4 * bins * 8)) return -1;
+    ps.hist = (uint64_t *)g.histpsum.p;
+    ps.psum = ps.hist + 2 * bins;
+    RelArgs r1 = nrel > 1 ? ps.r[1] : RelArgs{nullptr, nullptr, nullptr, 0, 64, 0};
+
+    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    hipLaunchKernelGGL(k_hist, dim3(max_tiles, nrel), dim3(WAVE), lds, g.stream, ps.r[0], r1, bits);
+    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    hipLaunchKernelGGL(k_scan_chunks, dim3((bins + 255) / 256, ps.chunks, nrel), dim3(256), 0, g.stream, ps.r[0], r1,
+                       bits, ps.chunks, (uint64_t *)g.chunk.p);
+    hipLaunchKernelGGL(k_scan_bins, dim3(nrel), dim3(1024), 0, g.stream, bits, ps.chunks, (uint64_t *)g.chunk.p,
+                       ps.hist, ps.psum);
+    hipLaunchKernelGGL(k_scan_apply, dim3((bins + 255) / 256, ps.chunks, nrel), dim3(256), 0, g.stream, ps.r[0], r1,
+                       bits, ps.chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)ps.psum);
+    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    hipLaunchKernelGGL(k_scatter, dim3(max_tiles, nrel), dim3(WAVE), lds, g.stream, ps.r[0], r1, bits);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+// The whole device-side join.  out == nullptr && use_ctx_out: the pairs land in the
+// context's own buffer (grown after the count pass), returned through *ctx_out.
+int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
+                uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
+{
+    if (ctx_init()) return -1;
+    rhj_stats &st = g.stats;
+    const float keep_h2d = st.ms_h2d;
+    memset(&st, 0, sizeof(st));
+    st.ms_h2d = keep_h2d;
+    st.n_r = nR; st.n_s = nS; st.radix_bits = g.bits;
+    *matches = 0;
+    if (ctx_out) *ctx_out = nullptr;
+    if (nR == 0 || nS == 0) return 0;                         // rhjoin.c:15-16
+    if (nR >= (1ull << 32) || nS >= (1ull << 32)) {
+        fprintf(stderr, "rhj: relations of 2^32 tuples or more are not supported (offsets are 32-bit; the reference "
+                        "itself is limited to 2^31-1, SURVEY.md finding 9)\n");
+        return -2;
+    }
+    const int bits = g.bits;
+    const uint32_t bins = 1u << bits;
+
+    PartState ps;
+    if (ensure(g.partR, nR * sizeof(rhj_tuple)) || ensure(g.partS, nS * sizeof(rhj_tuple))) return -1;
+    ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0};
+    ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0};
+    tile_geometry(nR, bits, &ps.r[0].tile_len, &ps.r[0].tiles);
+    tile_geometry(nS, bits, &ps.r[1].tile_len, &ps.r[1].tiles);
+    if (ensure(g.cntR, (size_t)ps.r[0].tiles * bins * 4) || ensure(g.cntS, (size_t)ps.r[1].tiles * bins * 4)) return -1;
+    ps.r[0].cnt = (uint32_t *)g.cntR.p;
+    ps.r[1].cnt = (uint32_t *)g.cntS.p;
+    if (run_partition(ps, bits, 2)) return -1;
+
+    // ---- plan
+    const uint32_t unit_lds = 65536, unit_hbm = 8192, build_chunk = 4096;
+    uint32_t lds_max_slots = (LDS_BUDGET - LDS_RESERVED) / 4;
+    uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);      // load factor <= 0.8
+    if (lds_cap > 65534) lds_cap = 65534;                                 // 16-bit position + 1
+    if (g.force_hbm) lds_cap = 0;
+    const uint64_t max_units = (uint64_t)bins + (nR + nS) / unit_hbm + 2;
+    const uint64_t max_bunits = (uint64_t)bins + (nR + nS) / build_chunk + 2;
+    if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) ||
+        ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) || ensure(g.summary, sizeof(PlanSummary)) ||
+        ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8))
+        return -1;
+    PlanArgs pa;
+    pa.histR = ps.hist; pa.histS = ps.hist + bins;
+    pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p;
+    pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
+    pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots;
+    pa.unit_lds = unit_lds; pa.unit_hbm = unit_hbm; pa.build_chunk = build_chunk;
+    HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+    PlanSummary *hs = (PlanSummary *)g.pin;
+    HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #1: launch geometry
+    const PlanSummary plan = *hs;
+    st.units = plan.units; st.hbm_units = plan.hbm_units; st.max_build = plan.max_build_lds;
+    st.table_slots = plan.hbm_slots;
+
+    JoinArgs ja;
+    ja.partR = (const rhj_tuple *)g.partR.p; ja.partS = (const rhj_tuple *)g.partS.p;
+    ja.histR = ps.hist; ja.histS = ps.hist + bins; ja.psumR = ps.psum; ja.psumS = ps.psum + bins;
+    ja.units = (const Unit *)g.units.p; ja.meta = (const BucketMeta *)g.meta.p;
+    ja.summary = (const PlanSummary *)g.summary.p;
+    ja.tables = nullptr; ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p;
+    ja.out = nullptr; ja.out_capacity = 0;
+
+    HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
+    if (plan.hbm_slots) {
+        if (ensure(g.tables, plan.hbm_slots * 8)) return -1;
+        ja.tables = (uint64_t *)g.tables.p;
+        HIP_TRY(hipMemsetAsync(g.tables.p, 0, plan.hbm_slots * 8, g.stream));
+        hipLaunchKernelGGL(k_build_hbm, dim3((unsigned)plan.build_units), dim3(256), 0, g.stream, ja,
+                           (const Unit *)g.bunits.p);
+    }
+
+    const uint32_t slots_max = (uint32_t)plan.max_lds_slots;
+    const bool big = (size_t)slots_max * 4 > 40 * 1024;       // large tables: one 1024-thread workgroup per CU
+    const size_t table_bytes = ((size_t)slots_max * 4 + 15) & ~(size_t)15;
+    const size_t lds_bytes = table_bytes + ((big ? 1024 : 256) / 64 + 1) * 8;
+    HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
+    if (plan.units) {
+        if (big) hipLaunchKernelGGL((k_probe<1024, false>), dim3((unsigned)plan.units), dim3(1024), lds_bytes, g.stream, ja, slots_max);
+        else     hipLaunchKernelGGL((k_probe<256, false>), dim3((unsigned)plan.units), dim3(256), lds_bytes, g.stream, ja, slots_max);
+    }
+    HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
+                       (const uint64_t *)&((PlanSummary *)g.summary.p)->units, (uint64_t)0,
+                       &((PlanSummary *)g.summary.p)->matches);
+    HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #2: match count -> output size
+    const uint64_t M = hs->matches;
+    *matches = M;
+    st.matches = M;
+
+    int rc = 0;
+    if (use_ctx_out) {
+        if (ensure(g.out, (M ? M : 1) * sizeof(rhj_result_tuple))) return -1;
+        out = (rhj_result_tuple *)g.out.p;
+        out_capacity = M;
+        if (ctx_out) *ctx_out = out;
+    } else if (M > out_capacity) {
+        rc = 1;
+    }
+    HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+    if (plan.units && M && out && out_capacity) {
+        ja.out = out; ja.out_capacity = out_capacity;
+        if (big) hipLaunchKernelGGL((k_probe<1024, true>), dim3((unsigned)plan.units), dim3(1024), lds_bytes, g.stream, ja, slots_max);
+        else     hipLaunchKernelGGL((k_probe<256, true>), dim3((unsigned)plan.units), dim3(256), lds_bytes, g.stream, ja, slots_max);
+    }
+    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
+    st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
+    st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
+    st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
+    st.ms_build = ev_ms(g.ev[ST_BUILD], g.ev[ST_COUNT]);
+    st.ms_count = ev_ms(g.ev[ST_COUNT], g.ev[ST_OFFSETS]);
+    st.ms_offsets = ev_ms(g.ev[ST_OFFSETS], g.ev[ST_PROBE]);
+    st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
+    st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    return rc;
+}
+
+int op_code(char op)
+{
+    return op == '<' ? 0 : op == '>' ? 1 : op == '=' ? 2 : -1;
+}
+
+int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char op, uint64_t value, uint64_t *d_out,
+                  bool use_ctx_out, uint64_t **ctx_out, uint64_t *hits)
+{
+    if (ctx_init()) return -1;
+    *hits = 0;
+    if (ctx_out) *ctx_out = nullptr;
+    const int oc = op_code(op);
+    if (oc < 0) return -3;
+    if (n == 0) return 0;
+    const uint64_t tiles = (n + FILTER_TILE - 1) / FILTER_TILE;
+    if (ensure(g.fmask, ((n + 63) / 64 + FILTER_ROUNDS * 4) * 8) || ensure(g.ftile, tiles * 8) ||
+        ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary)))
+        return -1;
+    if (use_ctx_out) {
+        if (ensure(g.fout, n * 8)) return -1;
+        d_out = (uint64_t *)g.fout.p;
+        if (ctx_out) *ctx_out = d_out;
+    }
+    uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
+    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
+                       (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p,
+                       (const uint64_t *)nullptr, tiles, total);
+    hipLaunchKernelGGL(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
+                       (const uint64_t *)g.fbase.p, d_out);
+    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *hits = *(uint64_t *)g.pin;
+    memset(&g.stats, 0, sizeof(g.stats));
+    g.stats.n_r = n; g.stats.matches = *hits;
+    g.stats.ms_total = g.stats.ms_probe = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C-ABI
+
+extern "C" {
+
+int rhj_set_radix_bits(int bits)
+{
+    if (bits < 1 || bits > MAX_BITS) return -1;
+    g.bits = bits;
+    return 0;
+}
+int rhj_get_radix_bits(void) { return g.bits; }
+void rhj_set_empty_mode(int null_on_empty) { g.null_on_empty = null_on_empty; }
+void rhj_set_node_pairs(uint64_t pairs) { g.node_pairs = pairs; }
+void rhj_set_force_hbm_table(int on) { g.force_hbm = on; }
+int rhj_set_device(int ordinal)
+{
+    if (g.ready) return -1;
+    g.device = ordinal;
+    return 0;
+}
+void rhj_set_stream(void *s)
+{
+    if (g.own_stream && g.stream) { hipStreamDestroy(g.stream); g.own_stream = false; }
+    g.stream = (hipStream_t)s;
+    if (!s && g.ready) { hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking); g.own_stream = true; }
+}
+const rhj_stats *rhj_last_stats(void) { return &g.stats; }
+const char *rhj_version(void) { return "rhj-mi355x 0.1 (gfx950)"; }
+
+int rhj_join_device(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple *d_out,
+                    uint64_t out_capacity, uint64_t *matches)
+{
+    uint64_t m = 0;
+    const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, false, nullptr, &m);
+    if (matches) *matches = m;
+    return rc;
+}
+
+int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, uint64_t *h_hist, int64_t *h_psum)
+{
+    if (ctx_init()) return -1;
+    const int bits = g.bits;
+    const uint32_t bins = 1u << bits;
+    if (n >= (1ull << 32)) return -2;
+    PartState ps;
+    ps.r[0] = RelArgs{d_in, d_out, nullptr, n, 0, 0};
+    tile_geometry(n, bits, &ps.r[0].tile_len, &ps.r[0].tiles);
+    if (ensure(g.cntR, (size_t)ps.r[0].tiles * bins * 4)) return -1;
+    ps.r[0].cnt = (uint32_t *)g.cntR.p;
+    if (run_partition(ps, bits, 1)) return -1;
+    HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+    uint64_t *hh = (uint64_t *)malloc((size_t)2 * bins * 8);
+    if (!hh) return -1;
+    HIP_TRY(hipMemcpyAsync(hh, ps.hist, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(hh + bins, ps.psum, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (uint32_t b = 0; b < bins; ++b) {
+        if (h_hist) h_hist[b] = hh[b];
+        if (h_psum) h_psum[b] = hh[b] ? (int64_t)hh[bins + b] : -1;      // preprocess.c:336-347
+    }
+    free(hh);
+    memset(&g.stats, 0, sizeof(g.stats));
+    g.stats.n_r = n; g.stats.radix_bits = bits;
+    g.stats.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
+    g.stats.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
+    g.stats.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
+    g.stats.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_PLAN]);
+    return 0;
+}
+
+int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char op, uint64_t value,
+                      uint64_t *d_out, uint64_t *hits)
+{
+    uint64_t h = 0;
+    const int rc = filter_device(d_col, d_sel, n, op, value, d_out, false, nullptr, &h);
+    if (hits) *hits = h;
+    return rc;
+}
+
+void rhj_release(void)
+{
+    if (!g.ready) return;
+    hipStreamSynchronize(g.stream);
+    Buf *all[] = {&g.partR, &g.partS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.units, &g.bunits, &g.meta,
+                  &g.summary, &g.ucount, &g.ubase, &g.tables, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask,
+                  &g.ftile, &g.fbase, &g.fout};
+    for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    for (auto &kv : g.columns) hipFree(kv.second);
+    g.columns.clear();
+}
+
+// ---- host-side staging used by rhj_abi.c (not part of the public header) ----
+
+// Upload both relations, join, and copy the pairs back into `node_pairs`-sized
+// chunks handed to `sink(ctx, chunk_index, ptr_to_fill, pairs)`-allocated memory.
+int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS, uint64_t *matches,
+                  void *(*alloc_chunk)(void *ctx, uint64_t pairs), void *ctx, uint64_t node_pairs)
+{
+    *matches = 0;
+    if (ctx_init()) return -1;
+    if (nR == 0 || nS == 0) return 0;
+    if (ensure(g.inR, nR * sizeof(rhj_tuple)) || ensure(g.inS, nS * sizeof(rhj_tuple))) return -1;
+    HIP_TRY(hipEventRecord(g.ev_x[0], g.stream));
+    HIP_TRY(hipMemcpyAsync(g.inR.p, R, nR * sizeof(rhj_tuple), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.inS.p, S, nS * sizeof(rhj_tuple), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipEventRecord(g.ev_x[1], g.stream));
+    rhj_result_tuple *d_out = nullptr;
+    uint64_t M = 0;
+    const int rc = join_device((const rhj_tuple *)g.inR.p, nR, (const rhj_tuple *)g.inS.p, nS, nullptr, 0, true, &d_out, &M);
+    if (rc < 0) return rc;
+    g.stats.ms_h2d = ev_ms(g.ev_x[0], g.ev_x[1]);
+    *matches = M;
+    if (M == 0) return 0;
+    if (node_pairs == 0) node_pairs = M;
+    HIP_TRY(hipEventRecord(g.ev_x[2], g.stream));
+    for (uint64_t at = 0; at < M; at += node_pairs) {
+        const uint64_t cnt = M - at < node_pairs ? M - at : node_pairs;
+        void *dst = alloc_chunk(ctx, cnt);
+        if (!dst) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)cnt); return -1; }
+        HIP_TRY(hipMemcpyAsync(dst, d_out + at, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream));
+    }
+    HIP_TRY(hipEventRecord(g.ev_x[3], g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.stats.ms_d2h = ev_ms(g.ev_x[2], g.ev_x[3]);
+    return 0;
+}
+
+static void *column_device(const uint64_t *host_col, uint64_t rows)
+{
+    auto key = std::make_pair((const void *)host_col, (size_t)rows);
+    auto it = g.columns.find(key);
+    if (it != g.columns.end()) return it->second;
+    void *d = nullptr;
+    if (hipMalloc(&d, (rows ? rows : 1) * 8) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(d, host_col, rows * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) { hipFree(d); return nullptr; }
+    g.columns[key] = d;
+    return d;
+}
+
+int rhj_register_relation_map(const rhj_relation_map *map, int num_relations)
+{
+    if (ctx_init()) return -1;
+    for (int r = 0; r < num_relations; ++r)
+        for (uint64_t c = 0; c < map[r].num_columns; ++c)
+            if (!column_device(map[r].columns[c], map[r].num_tuples)) return -1;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+// Filter on a host column (cached on the device after first use) with an optional
+// host row-id indirection vector; ids come back in `node_ids`-sized chunks.
+int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel, uint64_t n, char op, uint64_t value,
+                    uint64_t *hits, void *(*alloc_chunk)(void *ctx, uint64_t ids), void *ctx, uint64_t node_ids)
+{
+    *hits = 0;
+    if (ctx_init()) return -1;
+    if (op_code(op) < 0) return -3;
+    if (n == 0) return 0;
+    const uint64_t *d_col = (const uint64_t *)column_device(col, col_rows);
+    if (!d_col) { fprintf(stderr, "rhj: cannot stage column on the device\n"); return -1; }
+    const uint64_t *d_sel = nullptr;
+    if (sel) {
+        if (ensure(g.fcol_sel, n * 8)) return -1;
+        HIP_TRY(hipMemcpyAsync(g.fcol_sel.p, sel, n * 8, hipMemcpyHostToDevice, g.stream));
+        d_sel = (const uint64_t *)g.fcol_sel.p;
+    }
+    uint64_t *d_out = nullptr, h = 0;
+    const int rc = filter_device(d_col, d_sel, n, op, value, nullptr, true, &d_out, &h);
+    if (rc) return rc;
+    *hits = h;
+    for (uint64_t at = 0; at < h; at += node_ids) {
+        const uint64_t cnt = h - at < node_ids ? h - at : node_ids;
+        void *dst = alloc_chunk(ctx, cnt);
+        if (!dst) return -1;
+        HIP_TRY(hipMemcpyAsync(dst, d_out + at, cnt * 8, hipMemcpyDeviceToHost, g.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int rhj_host_null_on_empty(void) { return g.null_on_empty; }
+uint64_t rhj_host_node_pairs(void) { return g.node_pairs; }
+
+}  // extern "C"
