@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py — probe throughput of the MI355X radix hash join (BASELINE.json metric).
+
+One "step" = one full RadixHashJoin on device-resident inputs (radix partition of both
+relations, plan, count pass, probe/emit pass), i.e. rhj_join_device() of include/rhj.h.
+value = probe-side tuples (nS) of all ranks / wall time, in 10^9 tuples/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|dense]
+
+Workloads (synthetic, row_id[i] = i, keys through the splitmix64
+finaliser so all 64 bits are populated):
+    c2    1M  x 1M   uniform FK,  8 radix bits      (BASELINE configs[1])
+    c3    100M x 100M uniform FK, 12 radix bits     (BASELINE configs[2]; default: the
+          configuration the HBM-roofline target is stated on — c2's 48 MB working set
+          lives in the Infinity Cache, so an HBM fraction is meaningless there)
+    c4    100M x 1B  Zipf(0.9),   12 radix bits     (BASELINE configs[3])
+N > 1: every rank joins its own independent relations of the same size (weak scaling:
+independent joins of a plan shard across GPUs with no data-path collective).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "c2": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="uniform", name="1Mx1M uniform u64 FK, 8 radix bits"),
+    "c3": dict(nR=100_000_000, nS=100_000_000, bits=12, dist="uniform", name="100Mx100M uniform u64 FK, 12 radix bits"),
+    "c4": dict(nR=100_000_000, nS=1_000_000_000, bits=12, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 12 radix bits"),
+    "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
+}
+
+
+def lsr(x, k):
+    """logical shift right on int64 tensors"""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def mix64(x):
+    """splitmix64 finaliser on int64 tensors (wrap-around arithmetic), = oracle orc_mix64"""
+    import torch
+    c1 = torch.tensor(0xbf58476d1ce4e5b9 - (1 << 64), dtype=torch.int64, device=x.device)
+    c2 = torch.tensor(0x94d049bb133111eb - (1 << 64), dtype=torch.int64, device=x.device)
+    x = x ^ lsr(x, 30)
+    x = x * c1
+    x = x ^ lsr(x, 27)
+    x = x * c2
+    x = x ^ lsr(x, 31)
+    return x
+
+
+def zipf_ranks(n, domain, theta, gen, device):
+    """Gray et al. Zipf generator, vectorised (float64)."""
+    import torch
+    zetan = 0.0
+    for a in range(1, domain + 1, 1 << 24):
+        b = min(domain + 1, a + (1 << 24))
+        zetan += float(torch.arange(a, b, device=device, dtype=torch.float64).pow(-theta).sum())
+    alpha = 1.0 / (1.0 - theta)
+    eta = (1.0 - (2.0 / domain) ** (1.0 - theta)) / (1.0 - (1.0 + 0.5 ** theta) / zetan)
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    for a in range(0, n, 1 << 26):
+        b = min(n, a + (1 << 26))
+        u = torch.rand(b - a, generator=gen, device=device, dtype=torch.float64)
+        uz = u * zetan
+        r = (domain * (eta * u - eta + 1.0).pow(alpha)).to(torch.int64)
+        r = torch.where(uz < 1.0 + 0.5 ** theta, torch.ones_like(r), r)
+        r = torch.where(uz < 1.0, torch.zeros_like(r), r)
+        out[a:b] = r.clamp_(0, domain - 1)
+    return out
+
+
+def make_relations(w, device, seed):
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    nR, nS = w["nR"], w["nS"]
+    R = torch.empty((nR, 2), dtype=torch.int64, device=device)
+    S = torch.empty((nS, 2), dtype=torch.int64, device=device)
+    if w["dist"] == "dense":
+        R[:, 0] = torch.arange(1, nR + 1, device=device)
+        S[:, 0] = torch.randint(1, nR + 1, (nS,), generator=gen, device=device)
+    else:
+        R[:, 0] = mix64(torch.randperm(nR, generator=gen, device=device))
+        if w["dist"] == "zipf":
+            S[:, 0] = mix64(zipf_ranks(nS, nR, 0.9, gen, device))
+        else:
+            for a in range(0, nS, 1 << 27):
+                b = min(nS, a + (1 << 27))
+                S[a:b, 0] = mix64(torch.randint(0, nR, (b - a,), generator=gen, device=device))
+    R[:, 1] = torch.arange(nR, device=device)
+    S[:, 1] = torch.arange(nS, device=device)
+    return R, S
+
+
+def check_properties(R, S, out, m, w):
+    """size-independent parity properties at full size (FK join, unique R keys)"""
+    import torch
+    assert m == w["nS"], "FK join must emit one pair per S tuple (got %d)" % m
+    step = max(1, m // (1 << 22))
+    idx = torch.arange(0, m, step, device=out.device)
+    p = out[idx]
+    assert bool((R[p[:, 0], 0] == S[p[:, 1], 0]).all()), "pair joins unequal keys"
+    # every S row id appears exactly once: the wrap-around sum is closed-form
+    assert int(out[:, 1].sum()) == (w["nS"] * (w["nS"] - 1) // 2) % (1 << 63), "S row ids are not a permutation"
+    b = S[p[:, 1], 0] & ((1 << w["bits"]) - 1)
+    assert bool((b[1:] >= b[:-1]).all()), "buckets not ascending"
+
+
+def cpu_baseline(w):
+    """The reference's own code (oracle/_ref, THREADS=1 build of rhjoin.c) — or, when that
+    binary is absent, this repo's restatement (oracle/rhj_oracle.c) — timed on the host cores
+    over a bounded sample of the same workload (same distribution and radix bits)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    o = pyoracle.Oracle()
+    scale = 10 if w["nS"] > w["nR"] else 1
+    nR = min(w["nR"], 8_000_000 if scale == 1 else 2_000_000)
+    nS = nR * scale
+    R = o.generate(nR, 3 if w["dist"] == "dense" else 0, 0, 0.0, 42)
+    S = o.generate(nS, {"uniform": 1, "zipf": 2, "dense": 4}[w["dist"]], nR, 0.9, 43)
+    if w["dist"] == "dense":
+        S["value"] += 1
+    if pyoracle.ref_available(w["bits"], 1):
+        ref = pyoracle.Reference(w["bits"], 1)
+        _, info = ref.join(R, S, with_info=True)
+        secs, kind = info["seconds"], "reference"
+    else:
+        t = time.time(); o.join(R, S, w["bits"]); secs = time.time() - t
+        kind = "port"
+    return {"value": nS / secs / 1e9, "unit": "10^9 probe tuples/s", "cores": 1, "kind": kind,
+            "sample": "%dx%d %s, %d radix bits, one RadixHashJoin call, %.2f s" % (nR, nS, w["dist"], w["bits"], secs),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-hbm-table", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    w = WORKLOADS[args.workload]
+    mod = importlib.import_module("sigmod-2018_amd")
+    rhj = mod.RHJ(device=local)
+    rhj.set_bits(w["bits"])
+    if args.force_hbm_table:
+        rhj.lib.rhj_set_force_hbm_table(1)
+    dev = rhj.dev
+    R, S = make_relations(w, dev, 1234 + rank)
+    cap = w["nS"]
+    out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+    import ctypes as C
+    m = C.c_uint64(0)
+
+    def step():
+        rc = rhj.lib.rhj_join_device(R.data_ptr(), w["nR"], S.data_ptr(), w["nS"], out.data_ptr(), cap, C.byref(m))
+        if rc != 0:
+            raise RuntimeError("rhj_join_device rc=%d" % rc)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if rank == 0 or True:
+        check_properties(R, S, out, m.value, w)
+    keys = ("ms_hist", "ms_scan", "ms_scatter", "ms_plan", "ms_build", "ms_count", "ms_offsets", "ms_probe", "ms_total")
+    acc = dict.fromkeys(keys, 0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = rhj.stats()
+        for k in keys:
+            acc[k] += st[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = rhj.stats()
+    stage = {k: acc[k] / args.steps for k in keys}
+
+    if rank == 0:
+        nR, nS, M = w["nR"], w["nS"], m.value
+        probe_bytes = 16 * nS + 16 * nR + 16 * M          # probe kernel
+        count_bytes = 16 * nS + 16 * nR
+        scatter_bytes = 32 * (nR + nS)                    # 16 B read + 16 B written per AoS tuple
+        hist_bytes = 16 * (nR + nS)                       # AoS key read (stride-16)
+
+        def gbs(b, ms):
+            return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        res = {
+            "metric": "probe throughput (10^9 tuples/s) + achieved HBM GB/s",
+            "value": world * nS * args.steps / elapsed / 1e9,
+            "unit": "10^9 probe tuples/s (whole RadixHashJoin, inputs resident in HBM)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": w["name"], "id": args.workload, "nR": nR, "nS": nS, "radix_bits": w["bits"],
+                       "matches": M, "parallelism": "independent join per GPU" if world > 1 else "1 GPU",
+                       "units": st["units"], "hbm_table_units": st["hbm_units"], "max_build_side": st["max_build"]},
+            "roofline": {"bound": "hbm", "kernel": "k_probe<WRITE> (probe + emit)",
+                         "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"]},
+            "kernels": {
+                "probe_tuples_per_s_e9": nS / (stage["ms_probe"] * 1e-3) / 1e9 if stage["ms_probe"] > 0 else 0.0,
+                "count": {"ms": stage["ms_count"], "GBps": gbs(count_bytes, stage["ms_count"])},
+                "scatter": {"ms": stage["ms_scatter"], "GBps": gbs(scatter_bytes, stage["ms_scatter"])},
+                "hist": {"ms": stage["ms_hist"], "GBps": gbs(hist_bytes, stage["ms_hist"])},
+                "scan": {"ms": stage["ms_scan"]}, "plan": {"ms": stage["ms_plan"]},
+                "build_hbm": {"ms": stage["ms_build"]}, "offsets": {"ms": stage["ms_offsets"]},
+                "gpu_total_ms": stage["ms_total"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
