@@ -34,7 +34,6 @@ struct Buf {
 
 constexpr int MAX_BITS = 12;
 constexpr uint32_t LDS_BUDGET = 160 * 1024;       // bytes per workgroup on gfx950
-constexpr uint32_t LDS_RESERVED = 512;            // scan scratch behind the table
 
 enum Stage { ST_HIST, ST_SCAN, ST_SCATTER, ST_PLAN, ST_BUILD, ST_COUNT, ST_OFFSETS, ST_PROBE, ST_END, ST_N };
 
@@ -49,7 +48,8 @@ struct Ctx {
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
-    Buf partR, partS, cntR, cntS, chunk, histpsum, units, bunits, meta, summary, ucount, ubase, tables;
+    Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
+        ucount, ubase, tab32, tab64;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
@@ -94,61 +94,91 @@ int ctx_init()
     for (auto &ev : g.ev_x) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
     // dynamic LDS above 64 KiB has to be requested per kernel
-    const int big = LDS_BUDGET;
-    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_probe<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     g.ready = true;
     return 0;
 }
 
-void tile_geometry(uint64_t n, int bits, uint32_t *tile_len, uint32_t *tiles)
-{
-    // one wave per tile; at 12 bits the 16 KiB of LDS counters admit 10 waves per CU
-    const uint64_t max_tiles = bits >= 11 ? 2560 : 4096;
-    uint64_t t = (n + 2047) / 2048;
-    if (t < 1) t = 1;
-    if (t > max_tiles) t = max_tiles;
-    uint64_t len = (n + t - 1) / t;
-    len = (len + 63) / 64 * 64;
-    if (len == 0) len = 64;
-    *tile_len = (uint32_t)len;
-    *tiles = (uint32_t)((n + len - 1) / len);
-    if (*tiles == 0) *tiles = 1;
-}
-
 struct PartState {
-    RelArgs  r[2];
-    uint64_t *hist, *psum;   // [2][bins] each
-    uint32_t chunks;
+    RelArgs  r[2];           // in = caller's input, out = final partitioned array
+    rhj_tuple *tmp[2];       // intermediate of the two-pass path
+    uint64_t *hist, *psum;   // [2][bins] of the join's radix (filled by run_partition)
 };
 
-// hist + scan + scatter for one or two relations (r[1].n == 0 and tiles == 0 to skip)
+uint32_t tiles_for(uint64_t n)
+{
+    const uint64_t t = (n + PT_TILE - 1) / PT_TILE;
+    return (uint32_t)(t ? t : 1);
+}
+
+size_t scatter_lds_bytes(int bits)
+{
+    const size_t bins = (size_t)1 << bits;
+    return (size_t)PT_TILE * 16 + (PT_WAVES + 2) * bins * 4 + (PT_BLOCK / 64 + 1) * 8 + 16;
+}
+
+// one stable pass over both relations: per-tile histogram, scan, LDS-staged scatter
+int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int full_bits, uint64_t *hist, uint64_t *psum,
+                   bool first)
+{
+    const uint32_t bins = 1u << bits;
+    uint32_t max_tiles = r0.tiles;
+    if (nrel > 1 && r1.tiles > max_tiles) max_tiles = r1.tiles;
+    const uint32_t chunks = max_tiles >= 256 ? 32 : 1;
+    if (ensure(g.chunk, (size_t)2 * chunks * bins * 8)) return -1;
+    const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
+    const size_t hist_lds = ((size_t)bins + (full_bits ? ((size_t)1 << full_bits) : 0)) * 4;
+    if (first) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    hipLaunchKernelGGL(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), hist_lds, g.stream, r0, r1, shift, bits,
+                       full_bits, (uint32_t *)g.fullhist.p);
+    if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    hipLaunchKernelGGL(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
+                       chunks, (uint64_t *)g.chunk.p);
+    hipLaunchKernelGGL(k_scan_bins, dim3(nrel), dim3(1024), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist, psum);
+    hipLaunchKernelGGL(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
+                       chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
+    if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    hipLaunchKernelGGL(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1,
+                       shift, bits);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Stable radix partition of one or two relations on the low `bits` bits.  bits <= 8:
+// one pass.  bits 9..12: two LSD passes (low half into tmp, high half into out); the
+// bucket histogram of the full radix comes from the first pass' histogram kernel.
+// Stage events: ST_HIST..ST_SCAN first histogram, ST_SCAN..ST_SCATTER first scan,
+// ST_SCATTER..ST_PLAN everything else (scatter passes, second histogram + scan).
 int run_partition(PartState &ps, int bits, int nrel)
 {
     const uint32_t bins = 1u << bits;
-    const size_t lds = (size_t)bins * 4;
-    uint32_t max_tiles = 0;
-    for (int i = 0; i < nrel; ++i) max_tiles = ps.r[i].tiles > max_tiles ? ps.r[i].tiles : max_tiles;
-    ps.chunks = max_tiles >= 64 ? 32 : 1;
-    if (ensure(g.chunk, (size_t)2 * ps.chunks * bins * 8)) return -1;
-    if (ensure(g.histpsum, (size_t)4 * bins * 8)) return -1;
+    if (ensure(g.histpsum, (size_t)4 * bins * 8) || ensure(g.passhp, (size_t)4 * 256 * 8)) return -1;
     ps.hist = (uint64_t *)g.histpsum.p;
     ps.psum = ps.hist + 2 * bins;
-    RelArgs r1 = nrel > 1 ? ps.r[1] : RelArgs{nullptr, nullptr, nullptr, 0, 64, 0};
+    RelArgs none = RelArgs{nullptr, nullptr, nullptr, 0, 0, 0};
+    for (int i = 0; i < nrel; ++i) ps.r[i].tiles = tiles_for(ps.r[i].n);
+    if (ensure(g.cntR, (size_t)ps.r[0].tiles * 256 * 4)) return -1;
+    ps.r[0].cnt = (uint32_t *)g.cntR.p;
+    if (nrel > 1) {
+        if (ensure(g.cntS, (size_t)ps.r[1].tiles * 256 * 4)) return -1;
+        ps.r[1].cnt = (uint32_t *)g.cntS.p;
+    }
+    if (bits <= PT_MAX_BITS)
+        return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, 0, bits, 0, ps.hist, ps.psum, true);
 
-    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    hipLaunchKernelGGL(k_hist, dim3(max_tiles, nrel), dim3(WAVE), lds, g.stream, ps.r[0], r1, bits);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
-    hipLaunchKernelGGL(k_scan_chunks, dim3((bins + 255) / 256, ps.chunks, nrel), dim3(256), 0, g.stream, ps.r[0], r1,
-                       bits, ps.chunks, (uint64_t *)g.chunk.p);
-    hipLaunchKernelGGL(k_scan_bins, dim3(nrel), dim3(1024), 0, g.stream, bits, ps.chunks, (uint64_t *)g.chunk.p,
-                       ps.hist, ps.psum);
-    hipLaunchKernelGGL(k_scan_apply, dim3((bins + 255) / 256, ps.chunks, nrel), dim3(256), 0, g.stream, ps.r[0], r1,
-                       bits, ps.chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)ps.psum);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
-    hipLaunchKernelGGL(k_scatter, dim3(max_tiles, nrel), dim3(WAVE), lds, g.stream, ps.r[0], r1, bits);
+    const int lo = bits / 2, hi = bits - lo;
+    uint64_t *ph = (uint64_t *)g.passhp.p, *pp = ph + 2 * 256;
+    if (ensure(g.fullhist, (size_t)2 * bins * 4)) return -1;
+    HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
+    RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
+    RelArgs b0 = a0, b1 = a1;
+    a0.out = ps.tmp[0]; b0.in = ps.tmp[0];
+    if (nrel > 1) { a1.out = ps.tmp[1]; b1.in = ps.tmp[1]; }
+    if (partition_pass(a0, a1, nrel, 0, lo, bits, ph, pp, true)) return -1;
+    if (partition_pass(b0, b1, nrel, lo, hi, 0, ph, pp, false)) return -1;
+    hipLaunchKernelGGL(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
+                       ps.psum);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -186,66 +216,66 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     if (ensure(g.partR, nR * sizeof(rhj_tuple)) || ensure(g.partS, nS * sizeof(rhj_tuple))) return -1;
     ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0};
     ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0};
-    tile_geometry(nR, bits, &ps.r[0].tile_len, &ps.r[0].tiles);
-    tile_geometry(nS, bits, &ps.r[1].tile_len, &ps.r[1].tiles);
-    if (ensure(g.cntR, (size_t)ps.r[0].tiles * bins * 4) || ensure(g.cntS, (size_t)ps.r[1].tiles * bins * 4)) return -1;
-    ps.r[0].cnt = (uint32_t *)g.cntR.p;
-    ps.r[1].cnt = (uint32_t *)g.cntS.p;
+    ps.tmp[0] = ps.tmp[1] = nullptr;
+    if (bits > PT_MAX_BITS) {
+        if (ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple))) return -1;
+        ps.tmp[0] = (rhj_tuple *)g.tmpR.p; ps.tmp[1] = (rhj_tuple *)g.tmpS.p;
+    }
     if (run_partition(ps, bits, 2)) return -1;
 
     // ---- plan
-    const uint32_t unit_lds = 65536, unit_hbm = 8192, build_chunk = 4096;
-    uint32_t lds_max_slots = (LDS_BUDGET - LDS_RESERVED) / 4;
-    uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);      // load factor <= 0.8
-    if (lds_cap > 65534) lds_cap = 65534;                                 // 16-bit position + 1
+    const uint32_t build_chunk = 4096;
+    const uint32_t lds_max_slots = LDS_BUDGET / 4;                         // whole LDS holds one 32-bit table
+    uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
+    if (lds_cap > 65534) lds_cap = 65534;                                  // 16-bit position + 1
     if (g.force_hbm) lds_cap = 0;
-    const uint64_t max_units = (uint64_t)bins + (nR + nS) / unit_hbm + 2;
-    const uint64_t max_bunits = (uint64_t)bins + (nR + nS) / build_chunk + 2;
+    const uint64_t nmin = nR < nS ? nR : nS;
+    const uint64_t max_units = (uint64_t)bins + (nR + nS) / PR_UNIT + 2;
+    const uint64_t max_bunits = (uint64_t)bins + nmin / build_chunk + 2;
+    const uint64_t max_tab32 = nmin + nmin / 2 + (uint64_t)72 * bins + 64;
     if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) ||
-        ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) || ensure(g.summary, sizeof(PlanSummary)) ||
-        ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8))
+        ensure(g.ldsb, (size_t)bins * 4) || ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) ||
+        ensure(g.summary, sizeof(PlanSummary)) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
+        ensure(g.tab32, max_tab32 * 4))
         return -1;
     PlanArgs pa;
     pa.histR = ps.hist; pa.histS = ps.hist + bins;
-    pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p;
+    pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
-    pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots;
-    pa.unit_lds = unit_lds; pa.unit_hbm = unit_hbm; pa.build_chunk = build_chunk;
+    pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk; pa.pad = 0;
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     PlanSummary *hs = (PlanSummary *)g.pin;
     HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #1: launch geometry
     const PlanSummary plan = *hs;
-    st.units = plan.units; st.hbm_units = plan.hbm_units; st.max_build = plan.max_build_lds;
-    st.table_slots = plan.hbm_slots;
+    st.units = plan.units; st.hbm_units = plan.build_units; st.max_build = plan.max_build;
+    st.table_slots = plan.hbm_slots + plan.tab32_slots;
 
     JoinArgs ja;
     ja.partR = (const rhj_tuple *)g.partR.p; ja.partS = (const rhj_tuple *)g.partS.p;
     ja.histR = ps.hist; ja.histS = ps.hist + bins; ja.psumR = ps.psum; ja.psumS = ps.psum + bins;
     ja.units = (const Unit *)g.units.p; ja.meta = (const BucketMeta *)g.meta.p;
     ja.summary = (const PlanSummary *)g.summary.p;
-    ja.tables = nullptr; ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p;
+    ja.tab32 = (uint32_t *)g.tab32.p; ja.tab64 = nullptr;
+    ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p;
     ja.out = nullptr; ja.out_capacity = 0;
 
     HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
     if (plan.hbm_slots) {
-        if (ensure(g.tables, plan.hbm_slots * 8)) return -1;
-        ja.tables = (uint64_t *)g.tables.p;
-        HIP_TRY(hipMemsetAsync(g.tables.p, 0, plan.hbm_slots * 8, g.stream));
+        if (ensure(g.tab64, plan.hbm_slots * 8)) return -1;
+        ja.tab64 = (uint64_t *)g.tab64.p;
+        HIP_TRY(hipMemsetAsync(g.tab64.p, 0, plan.hbm_slots * 8, g.stream));
         hipLaunchKernelGGL(k_build_hbm, dim3((unsigned)plan.build_units), dim3(256), 0, g.stream, ja,
                            (const Unit *)g.bunits.p);
     }
+    if (plan.lds_buckets)
+        hipLaunchKernelGGL(k_build_lds, dim3((unsigned)plan.lds_buckets), dim3(BL_BLOCK), (size_t)plan.max_lds_slots * 4,
+                           g.stream, ja, (const uint32_t *)g.ldsb.p);
 
-    const uint32_t slots_max = (uint32_t)plan.max_lds_slots;
-    const bool big = (size_t)slots_max * 4 > 40 * 1024;       // large tables: one 1024-thread workgroup per CU
-    const size_t table_bytes = ((size_t)slots_max * 4 + 15) & ~(size_t)15;
-    const size_t lds_bytes = table_bytes + ((big ? 1024 : 256) / 64 + 1) * 8;
     HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
-    if (plan.units) {
-        if (big) hipLaunchKernelGGL((k_probe<1024, false>), dim3((unsigned)plan.units), dim3(1024), lds_bytes, g.stream, ja, slots_max);
-        else     hipLaunchKernelGGL((k_probe<256, false>), dim3((unsigned)plan.units), dim3(256), lds_bytes, g.stream, ja, slots_max);
-    }
+    if (plan.units)
+        hipLaunchKernelGGL((k_probe<false>), dim3((unsigned)plan.units), dim3(PR_BLOCK), 0, g.stream, ja);
     HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
                        (const uint64_t *)&((PlanSummary *)g.summary.p)->units, (uint64_t)0,
@@ -268,8 +298,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
     if (plan.units && M && out && out_capacity) {
         ja.out = out; ja.out_capacity = out_capacity;
-        if (big) hipLaunchKernelGGL((k_probe<1024, true>), dim3((unsigned)plan.units), dim3(1024), lds_bytes, g.stream, ja, slots_max);
-        else     hipLaunchKernelGGL((k_probe<256, true>), dim3((unsigned)plan.units), dim3(256), lds_bytes, g.stream, ja, slots_max);
+        hipLaunchKernelGGL((k_probe<true>), dim3((unsigned)plan.units), dim3(PR_BLOCK), 0, g.stream, ja);
     }
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     HIP_TRY(hipGetLastError());
@@ -376,9 +405,11 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
     if (n >= (1ull << 32)) return -2;
     PartState ps;
     ps.r[0] = RelArgs{d_in, d_out, nullptr, n, 0, 0};
-    tile_geometry(n, bits, &ps.r[0].tile_len, &ps.r[0].tiles);
-    if (ensure(g.cntR, (size_t)ps.r[0].tiles * bins * 4)) return -1;
-    ps.r[0].cnt = (uint32_t *)g.cntR.p;
+    ps.tmp[0] = ps.tmp[1] = nullptr;
+    if (bits > PT_MAX_BITS) {
+        if (ensure(g.tmpR, (n ? n : 1) * sizeof(rhj_tuple))) return -1;
+        ps.tmp[0] = (rhj_tuple *)g.tmpR.p;
+    }
     if (run_partition(ps, bits, 1)) return -1;
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
     uint64_t *hh = (uint64_t *)malloc((size_t)2 * bins * 8);
@@ -413,9 +444,9 @@ void rhj_release(void)
 {
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
-    Buf *all[] = {&g.partR, &g.partS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.units, &g.bunits, &g.meta,
-                  &g.summary, &g.ucount, &g.ubase, &g.tables, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask,
-                  &g.ftile, &g.fbase, &g.fout};
+    Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.tab32,
+                  &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);
     g.columns.clear();

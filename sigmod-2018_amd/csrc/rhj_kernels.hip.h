@@ -2,13 +2,20 @@
 // join and the filter scan.  Integer / indexing work only: the roofline is HBM.
 //
 // Reference loops these kernels replace (file:line in VagelisN/Sigmod-2018):
-//   k_hist           HistJob                      preprocess.c:181-195
+//   k_hist_tiles     HistJob                      preprocess.c:181-195
 //   k_scan_*         hist merge + psum            preprocess.c:83-102 / :328-340
-//   k_scatter        SerialReorderArray scatter   preprocess.c:349-359 (stable)
+//   k_scatter_lds    SerialReorderArray scatter   preprocess.c:349-359 (stable)
 //   k_plan           bucket loop / side choice    rhjoin.c:79-102 (>= picks the probe side)
-//   k_build_hbm      InitIndex + CreateIndex      rhjoin.c:253-273, :219-250
-//   k_probe          CreateIndex + GetResults     rhjoin.c:219-250, :141-217
+//   k_build_lds / k_build_hbm   InitIndex + CreateIndex   rhjoin.c:253-273, :219-250
+//   k_probe          GetResults                   rhjoin.c:141-217
 //   k_filter_*       Filter                       filter.c:110-183
+//
+// Partition.  A pass handles at most 8 digit bits: a workgroup ranks a 4096-tuple
+// tile stably (wave match-any ballots + per-wave LDS counters), stages it in LDS in
+// digit order and writes every digit run as full 16-byte-per-lane coalesced stores
+// (a direct 4096-way scatter of 16-byte tuples measured 2.6x write amplification and
+// 834 GB/s on MI355X: profiles/r01a).  Wider radixes (9..12 bits) run two stable LSD
+// passes (low half, then high half), which yields the same stable order as one pass.
 //
 // Hash index.  The reference chains bucket positions in DESCENDING order behind a
 // prime-modulus slot (CreateIndex walks last->first and appends at the tail), which
@@ -20,11 +27,12 @@
 // duplicates in descending position — the reference's chain order — and can stop at
 // the first entry whose tag is smaller.  Tags only pre-filter: every candidate is
 // verified against the build tuple's full 64-bit key, so results are exact.
-//   * table in LDS   (32-bit entries, 16-bit tag, 16-bit position) when the build
-//     side of the bucket has <= lds_cap tuples: one workgroup per probe unit builds
-//     it from the bucket's build side and streams the probe side through it;
-//   * table in HBM   (64-bit entries, 32-bit tag, 32-bit position) otherwise, built
-//     by k_build_hbm with global atomics and shared by all probe units of the bucket.
+// Tables live in HBM (L2-resident while their bucket is being probed):
+//   * 32-bit entries (16-bit tag, 16-bit position), built in LDS by one workgroup per
+//     bucket and dumped, when the bucket's build side has <= lds_cap tuples;
+//   * 64-bit entries (32-bit tag, 32-bit position), built with global atomics, else.
+// Probe units are tiles of 2048 probe tuples in canonical order; any number of
+// workgroups share a bucket's table, so a hot bucket costs no extra build work.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,36 +42,36 @@ namespace rhj {
 
 constexpr int WAVE = 64;
 
-struct RelArgs {                 // one relation through the partition kernels
+struct RelArgs {                 // one relation through one partition pass
     const rhj_tuple *in;
     rhj_tuple       *out;
     uint32_t        *cnt;        // [tiles][bins] counts, then (after scan) start offsets
     uint64_t         n;
-    uint32_t         tile_len;   // tuples per tile (multiple of 64)
     uint32_t         tiles;
+    uint32_t         pad;
 };
 
-struct Unit {                    // one probe work unit, in canonical order
-    uint64_t off;                // offset inside the bucket's probe side
+struct Unit {
+    uint64_t off;                // offset inside the bucket's probe (or build) side
     uint32_t bucket;
-    uint32_t count;              // probe tuples in this unit
+    uint32_t count;
 };
 
 struct BucketMeta {
-    uint64_t table_off;          // HBM mode: first slot in the table arena
-    uint32_t slots;              // LDS mode: slot count; HBM mode: log2(slot count)
-    uint32_t mode;               // 0 inactive, 1 LDS table, 2 HBM table
+    uint64_t table_off;          // first slot in the 32-bit or 64-bit table arena
+    uint32_t slots;              // 32-bit table: slot count; 64-bit table: log2(slot count)
+    uint32_t mode;               // 0 inactive, 1 32-bit table (LDS-built), 2 64-bit table
 };
 
 struct PlanSummary {
     uint64_t units;              // probe units
-    uint64_t build_units;        // HBM build chunks
-    uint64_t hbm_slots;          // total 64-bit slots of all HBM tables
-    uint64_t max_build_lds;      // largest build side among LDS buckets
-    uint64_t hbm_units;          // probe units that use an HBM table
-    uint64_t max_lds_slots;      // largest LDS slot count
+    uint64_t build_units;        // 64-bit-table build chunks
+    uint64_t hbm_slots;          // total slots of all 64-bit tables
+    uint64_t lds_buckets;        // buckets with an LDS-built 32-bit table
+    uint64_t tab32_slots;        // total slots of all 32-bit tables
+    uint64_t max_lds_slots;      // largest 32-bit table
+    uint64_t max_build;          // largest build side
     uint64_t matches;            // filled by k_offsets
-    uint64_t pad;
 };
 
 struct JoinArgs {
@@ -72,7 +80,8 @@ struct JoinArgs {
     const Unit      *units;
     const BucketMeta*meta;
     const PlanSummary *summary;
-    uint64_t        *tables;         // HBM table arena
+    uint32_t        *tab32;          // 32-bit table arena
+    uint64_t        *tab64;          // 64-bit table arena
     uint64_t        *unit_count;     // [units] matches per unit (count pass)
     const uint64_t  *unit_base;      // [units] exclusive scan of unit_count
     rhj_result_tuple*out;
@@ -92,35 +101,93 @@ __device__ __forceinline__ uint64_t lanemask_lt()
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+template <int NT>
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *total, uint64_t *sm /*NT/64+1*/)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();                       // sm reuse across calls
+    if (lane == 63) sm[w] = x;
+    __syncthreads();
+    if (threadIdx.x < 64) {                // one wave scans the wave totals
+        const uint64_t t = threadIdx.x < NT / 64 ? sm[threadIdx.x] : 0;
+        uint64_t y = t;
+#pragma unroll
+        for (int d = 1; d < NT / 64; d <<= 1) {
+            const uint64_t z = __shfl_up(y, d, 64);
+            if ((int)threadIdx.x >= d) y += z;
+        }
+        if (threadIdx.x < NT / 64) sm[threadIdx.x] = y - t;
+        if (threadIdx.x == NT / 64 - 1) sm[NT / 64] = y;
+    }
+    __syncthreads();
+    if (total) *total = sm[NT / 64];
+    return sm[w] + x - v;
+}
+
 // ------------------------------------------------------------------ partition
 
-// Pass 1: per-tile digit histogram.  One wave per tile; LDS counters, one global
-// row write per tile.  Reads the key half of each 16-byte AoS tuple.
-__global__ __launch_bounds__(WAVE) void k_hist(RelArgs r0, RelArgs r1, int bits)
+constexpr int PT_BLOCK = 512;                     // threads per partition workgroup
+constexpr int PT_V = 8;                           // tuples per thread
+constexpr int PT_TILE = PT_BLOCK * PT_V;          // 4096 tuples = 64 KiB staged in LDS
+constexpr int PT_WAVES = PT_BLOCK / WAVE;
+constexpr int PT_MAX_BITS = 8;                    // digit bits per pass
+
+// Per-tile digit histogram of one pass: cnt[tile][digit] for digit = (key >> shift) & mask.
+// full_bits > 0 additionally accumulates the histogram of the low full_bits bits of the
+// key (the join's bucket histogram) into full_hist with one atomic per bin per workgroup.
+__global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits, int full_bits,
+                                                    uint32_t *full_hist /*[2][1<<full_bits]*/)
 {
     extern __shared__ uint32_t lds_u32[];
     const RelArgs &r = blockIdx.y ? r1 : r0;
-    if (blockIdx.x >= r.tiles) return;
     const uint32_t bins = 1u << bits, mask = bins - 1u;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t b = lane; b < bins; b += WAVE) lds_u32[b] = 0;
-    __syncthreads();
-    const uint64_t beg = (uint64_t)blockIdx.x * r.tile_len;
-    const uint64_t end = min(beg + (uint64_t)r.tile_len, r.n);
-    const rhj_tuple *in = r.in;
-    uint64_t i = beg + lane;
-    for (; i + 3 * WAVE < end; i += 4 * WAVE) {
-        const uint64_t k0 = in[i].value, k1 = in[i + WAVE].value;
-        const uint64_t k2 = in[i + 2 * WAVE].value, k3 = in[i + 3 * WAVE].value;
-        atomicAdd(&lds_u32[(uint32_t)k0 & mask], 1u);
-        atomicAdd(&lds_u32[(uint32_t)k1 & mask], 1u);
-        atomicAdd(&lds_u32[(uint32_t)k2 & mask], 1u);
-        atomicAdd(&lds_u32[(uint32_t)k3 & mask], 1u);
+    const uint32_t fbins = full_bits ? 1u << full_bits : 0u, fmask = fbins - 1u;
+    uint32_t *tile_h = lds_u32;                   // [bins]
+    uint32_t *full_h = lds_u32 + bins;            // [fbins]
+    for (uint32_t b = threadIdx.x; b < fbins; b += 256) full_h[b] = 0;
+    for (uint32_t tile = blockIdx.x; tile < r.tiles; tile += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) tile_h[b] = 0;
+        __syncthreads();
+        const uint64_t beg = (uint64_t)tile * PT_TILE;
+        const uint64_t end = min(beg + (uint64_t)PT_TILE, r.n);
+#pragma unroll 4
+        for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+            const uint64_t k = r.in[i].value;
+            atomicAdd(&tile_h[(uint32_t)(k >> shift) & mask], 1u);
+            if (full_bits) atomicAdd(&full_h[(uint32_t)k & fmask], 1u);
+        }
+        __syncthreads();
+        uint32_t *row = r.cnt + (size_t)tile * bins;
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) row[b] = tile_h[b];
+        __syncthreads();
     }
-    for (; i < end; i += WAVE) atomicAdd(&lds_u32[(uint32_t)in[i].value & mask], 1u);
-    __syncthreads();
-    uint32_t *row = r.cnt + (size_t)blockIdx.x * bins;
-    for (uint32_t b = lane; b < bins; b += WAVE) row[b] = lds_u32[b];
+    if (full_bits) {
+        __syncthreads();
+        uint32_t *dst = full_hist + (size_t)blockIdx.y * fbins;
+        for (uint32_t b = threadIdx.x; b < fbins; b += 256) {
+            const uint32_t v = full_h[b];
+            if (v) atomicAdd(&dst[b], v);
+        }
+    }
 }
 
 // Scan step 1: per (bin, chunk of tiles) column sums.
@@ -138,31 +205,8 @@ __global__ __launch_bounds__(256) void k_scan_chunks(RelArgs r0, RelArgs r1, int
     chunk_sum[((size_t)blockIdx.z * chunks + blockIdx.y) * bins + b] = s;
 }
 
-template <int NT>
-__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *total, uint64_t *sm /*NT/64+1*/)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint64_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();                       // sm reuse across calls
-    if (lane == 63) sm[w] = x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < NT / 64; ++i) { const uint64_t t = sm[i]; sm[i] = run; run += t; }
-        sm[NT / 64] = run;
-    }
-    __syncthreads();
-    if (total) *total = sm[NT / 64];
-    return sm[w] + x - v;
-}
-
-// Scan step 2 (one workgroup per relation): bucket totals -> hist, exclusive scan
-// over buckets -> psum, chunk sums -> exclusive chunk prefixes.
+// Scan step 2 (one workgroup per relation): digit totals -> hist, exclusive scan over
+// digits -> psum, chunk sums -> exclusive chunk prefixes.
 __global__ __launch_bounds__(1024) void k_scan_bins(int bits, uint32_t chunks, uint64_t *chunk_sum,
                                                     uint64_t *hist /*[2][bins]*/, uint64_t *psum /*[2][bins]*/)
 {
@@ -209,136 +253,206 @@ __global__ __launch_bounds__(256) void k_scan_apply(RelArgs r0, RelArgs r1, int 
     }
 }
 
-// Pass 2: stable scatter.  One wave per tile owns the tile's running offsets in LDS.
-// Per round of 64 tuples every lane takes a slot with an LDS atomic add (unique, any
-// order); lanes that share a digit with another lane of the round are then re-ranked
-// in lane order with ballots, which makes the placement the stable one whatever order
-// the LDS served the adds in.  Cost grows with the number of digits that repeat inside
-// a round, not with the number of digits.
-__global__ __launch_bounds__(WAVE) void k_scatter(RelArgs r0, RelArgs r1, int bits)
+// Bucket histogram (u32, from k_hist_tiles' atomics) -> u64 hist + exclusive psum.
+__global__ __launch_bounds__(1024) void k_full_psum(int bits, const uint32_t *full_hist, uint64_t *hist, uint64_t *psum)
 {
-    extern __shared__ uint32_t lds_u32[];
-    const RelArgs &r = blockIdx.y ? r1 : r0;
-    if (blockIdx.x >= r.tiles) return;
+    __shared__ uint64_t sm[1024 / 64 + 1];
+    const uint32_t bins = 1u << bits;
+    const uint32_t *f = full_hist + (size_t)blockIdx.x * bins;
+    uint64_t *h = hist + (size_t)blockIdx.x * bins, *p = psum + (size_t)blockIdx.x * bins;
+    const uint32_t per = (bins + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t mine = 0;
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) mine += f[b];
+    uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) {
+        h[b] = f[b];
+        p[b] = base;
+        base += f[b];
+    }
+}
+
+// One stable partition pass on digit = (key >> shift) & ((1 << bits) - 1), bits <= 8.
+// Tile order in memory is (wave, round, lane); a tuple's stable rank inside its digit is
+//   digit_start + (same digit in earlier waves) + (same digit in earlier rounds of this
+//   wave) + (same digit in lower lanes of this round)
+// computed with one match-any (bits ballots) per round and per-wave LDS counters — no
+// atomics, so the placement does not depend on any hardware ordering.
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
     const uint32_t bins = 1u << bits, mask = bins - 1u;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t *row = r.cnt + (size_t)blockIdx.x * bins;
-    for (uint32_t b = lane; b < bins; b += WAVE) lds_u32[b] = row[b];
-    __syncthreads();
-    const uint64_t beg = (uint64_t)blockIdx.x * r.tile_len;
-    const uint64_t end = min(beg + (uint64_t)r.tile_len, r.n);
-    const uint4 *in = reinterpret_cast<const uint4 *>(r.in);
-    uint4 *out = reinterpret_cast<uint4 *>(r.out);
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint32_t *delta = dstart + bins;                                           // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(delta + bins);                 // scan scratch
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= r.tiles) return;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    constexpr int U = 4;
-    for (uint64_t base = beg; base < end; base += U * WAVE) {
-        uint4 t[U];
-        bool ok[U];
+    const uint64_t beg = (uint64_t)tile * PT_TILE;
+    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+
+    for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+
+    uint4 t[PT_V];
+    bool ok[PT_V];
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint64_t i = base + (uint64_t)k * WAVE + lane;
-            ok[k] = i < end;
-            if (ok[k]) t[k] = in[i];
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
+        ok[k] = i < count;
+        if (ok[k]) t[k] = in[i];
+    }
+    __syncthreads();
+
+    uint32_t lrank[PT_V], dig[PT_V];
+    uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;
+        const uint32_t d = (uint32_t)(key >> shift) & mask;
+        dig[k] = d;
+        uint64_t peers = __ballot(ok[k]);
+        for (int b = 0; b < bits; ++b) {
+            const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
+            peers &= ((d >> b) & 1u) ? m : ~m;
         }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        uint32_t old = 0;
+        if (ok[k] && rank == 0) {                       // lowest lane of each digit group
+            old = mycnt[d];
+            mycnt[d] = old + (uint32_t)__popcll(peers);
+        }
+        const int leader = ok[k] ? __ffsll((unsigned long long)peers) - 1 : 0;
+        old = __shfl(old, leader, 64);
+        lrank[k] = old + rank;
+    }
+    __syncthreads();
+
+    // per digit: exclusive prefix over waves, digit totals
+    uint64_t mytotal = 0;
+    if (threadIdx.x < bins) {
+        uint32_t run = 0;
+        for (int ww = 0; ww < PT_WAVES; ++ww) {
+            const uint32_t c = wcnt[ww * bins + threadIdx.x];
+            wcnt[ww * bins + threadIdx.x] = run;
+            run += c;
+        }
+        mytotal = run;
+    }
+    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+    if (threadIdx.x < bins) {
+        dstart[threadIdx.x] = (uint32_t)ds;
+        delta[threadIdx.x] = r.cnt[(size_t)tile * bins + threadIdx.x] - (uint32_t)ds;   // mod 2^32
+    }
+    __syncthreads();
+
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t d = t[k].x & mask;
-            uint32_t old = 0, fin = 0;
-            if (ok[k]) old = atomicAdd(&lds_u32[d], 1u);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            if (ok[k]) fin = *reinterpret_cast<volatile uint32_t *>(&lds_u32[d]);
-            uint32_t dest = old;
-            uint64_t multi = __ballot(ok[k] && (fin - old) > 1u);
-            while (multi) {
-                const int leader = __ffsll((unsigned long long)multi) - 1;
-                const uint32_t dd = __shfl(d, leader, 64);
-                const bool in_group = ok[k] && d == dd;
-                const uint64_t g = __ballot(in_group);
-                if (in_group) dest = fin - (uint32_t)__popcll(g) + (uint32_t)__popcll(g & lt);
-                multi &= ~g;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            if (ok[k]) out[dest] = t[k];
+    for (int k = 0; k < PT_V; ++k)
+        if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
+    __syncthreads();
+
+    uint4 *out = reinterpret_cast<uint4 *>(r.out);
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t p = k * PT_BLOCK + threadIdx.x;
+        if (p < count) {
+            const uint4 v = stage[p];
+            const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+            const uint32_t d = (uint32_t)(key >> shift) & mask;
+            out[(uint32_t)(delta[d] + p)] = v;
         }
     }
 }
 
 // ----------------------------------------------------------------------- plan
 
+constexpr int PR_BLOCK = 256;                     // probe workgroup
+constexpr int PR_V = 4;                           // probe tuples per thread
+constexpr int PR_UNIT = PR_BLOCK * PR_V;          // 2048 probe tuples per unit
+
 struct PlanArgs {
     const uint64_t *histR, *histS;
     Unit           *units, *build_units;
+    uint32_t       *lds_buckets;    // list of buckets whose table is built in LDS
     BucketMeta     *meta;
     PlanSummary    *summary;
-    uint32_t        lds_cap;        // largest build side served by an LDS table
+    uint32_t        lds_cap;        // largest build side served by an LDS-built table
     uint32_t        lds_max_slots;  // LDS slot budget
-    uint32_t        unit_lds;       // probe tuples per unit, LDS buckets
-    uint32_t        unit_hbm;       // probe tuples per unit, HBM buckets
-    uint32_t        build_chunk;    // build tuples per HBM build unit
+    uint32_t        build_chunk;    // build tuples per 64-bit-table build unit
+    uint32_t        pad;
 };
+
+__device__ __forceinline__ uint32_t lds_slots_for(uint64_t bc, uint32_t max_slots)
+{
+    uint32_t s = (uint32_t)(bc + (bc >> 1)) + 4u;          // load factor <= 2/3 when it fits
+    s = (s + 3u) & ~3u;                                    // 16-byte dump granule
+    return min(max(s, 64u), max_slots);
+}
 
 __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
 {
     __shared__ uint64_t sm[1024 / 64 + 1];
-    __shared__ uint64_t red[4];
+    __shared__ unsigned long long red[2];
     const uint32_t bins = 1u << bits;
     const uint32_t per = (bins + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, bins);
-    if (threadIdx.x < 4) red[threadIdx.x] = 0;
+    if (threadIdx.x < 2) red[threadIdx.x] = 0;
 
-    uint64_t nu = 0, nbu = 0, slots = 0, hbm_units = 0;
+    uint64_t nu = 0, nbu = 0, slots64 = 0, nlds = 0, slots32 = 0;
     uint32_t max_build = 0, max_slots = 0;
     for (uint32_t b = b0; b < b1; ++b) {
         const uint64_t cR = a.histR[b], cS = a.histS[b];
         if (cR == 0 || cS == 0) continue;
         const uint64_t pc = cR >= cS ? cR : cS, bc = cR >= cS ? cS : cR;   // rhjoin.c:86 (>=)
+        nu += (pc + PR_UNIT - 1) / PR_UNIT;
+        max_build = max(max_build, (uint32_t)min(bc, (uint64_t)0xffffffffu));
         if (bc <= a.lds_cap) {
-            nu += (pc + a.unit_lds - 1) / a.unit_lds;
-            max_build = max(max_build, (uint32_t)bc);
-            uint32_t s = (uint32_t)(bc + (bc >> 1)) + 1u;
-            s = min(max(s, 64u), a.lds_max_slots);
+            const uint32_t s = lds_slots_for(bc, a.lds_max_slots);
+            nlds += 1; slots32 += s;
             max_slots = max(max_slots, s);
         } else {
-            const uint64_t u = (pc + a.unit_hbm - 1) / a.unit_hbm;
-            nu += u; hbm_units += u;
             nbu += (bc + a.build_chunk - 1) / a.build_chunk;
-            uint32_t lg = 64 - __clzll((unsigned long long)(2 * bc - 1));   // pow2 >= 2*bc
-            slots += 1ull << lg;
+            slots64 += 1ull << (64 - __clzll((unsigned long long)(2 * bc - 1)));   // pow2 >= 2*bc
         }
     }
-    uint64_t tot_u, tot_b, tot_s;
+    uint64_t tot_u, tot_b, tot_s64, tot_l, tot_s32;
     uint64_t ubase = block_excl_scan<1024>(nu, &tot_u, sm);
     uint64_t bbase = block_excl_scan<1024>(nbu, &tot_b, sm);
-    uint64_t sbase = block_excl_scan<1024>(slots, &tot_s, sm);
-    atomicMax((unsigned long long *)&red[0], (unsigned long long)max_build);
-    atomicMax((unsigned long long *)&red[1], (unsigned long long)max_slots);
-    atomicAdd((unsigned long long *)&red[2], (unsigned long long)hbm_units);
+    uint64_t s64base = block_excl_scan<1024>(slots64, &tot_s64, sm);
+    uint64_t lbase = block_excl_scan<1024>(nlds, &tot_l, sm);
+    uint64_t s32base = block_excl_scan<1024>(slots32, &tot_s32, sm);
+    atomicMax(&red[0], (unsigned long long)max_build);
+    atomicMax(&red[1], (unsigned long long)max_slots);
 
     for (uint32_t b = b0; b < b1; ++b) {
         const uint64_t cR = a.histR[b], cS = a.histS[b];
         BucketMeta m = {0, 0, 0};
         if (cR != 0 && cS != 0) {
             const uint64_t pc = cR >= cS ? cR : cS, bc = cR >= cS ? cS : cR;
-            uint32_t span;
             if (bc <= a.lds_cap) {
-                uint32_t s = (uint32_t)(bc + (bc >> 1)) + 1u;
-                m.slots = min(max(s, 64u), a.lds_max_slots);
+                m.slots = lds_slots_for(bc, a.lds_max_slots);
                 m.mode = 1;
-                span = a.unit_lds;
+                m.table_off = s32base;
+                s32base += m.slots;
+                a.lds_buckets[lbase++] = b;
             } else {
                 const uint32_t lg = 64 - __clzll((unsigned long long)(2 * bc - 1));
                 m.slots = lg;
                 m.mode = 2;
-                m.table_off = sbase;
-                sbase += 1ull << lg;
-                span = a.unit_hbm;
+                m.table_off = s64base;
+                s64base += 1ull << lg;
                 for (uint64_t o = 0; o < bc; o += a.build_chunk) {
                     Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min((uint64_t)a.build_chunk, bc - o);
                     a.build_units[bbase++] = u;
                 }
             }
-            for (uint64_t o = 0; o < pc; o += span) {
-                Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min((uint64_t)span, pc - o);
+            for (uint64_t o = 0; o < pc; o += PR_UNIT) {
+                Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min((uint64_t)PR_UNIT, pc - o);
                 a.units[ubase++] = u;
             }
         }
@@ -347,16 +461,15 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
     __syncthreads();
     if (threadIdx.x == 0) {
         PlanSummary s;
-        s.units = tot_u; s.build_units = tot_b; s.hbm_slots = tot_s;
-        s.max_build_lds = red[0]; s.max_lds_slots = red[1]; s.hbm_units = red[2];
-        s.matches = 0; s.pad = 0;
+        s.units = tot_u; s.build_units = tot_b; s.hbm_slots = tot_s64; s.lds_buckets = tot_l;
+        s.tab32_slots = tot_s32; s.max_lds_slots = red[1]; s.max_build = red[0]; s.matches = 0;
         *a.summary = s;
     }
 }
 
 // ---------------------------------------------------------------- hash tables
 
-// HBM table insert: one thread per build tuple of an HBM bucket.
+// 64-bit table insert (build side too large for LDS): one thread per build tuple.
 __global__ __launch_bounds__(256) void k_build_hbm(JoinArgs a, const Unit *build_units)
 {
     if (blockIdx.x >= a.summary->build_units) return;
@@ -365,7 +478,7 @@ __global__ __launch_bounds__(256) void k_build_hbm(JoinArgs a, const Unit *build
     const bool flip = a.histR[b] < a.histS[b];
     const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
     const BucketMeta m = a.meta[b];
-    unsigned long long *tbl = (unsigned long long *)(a.tables + m.table_off);
+    unsigned long long *tbl = (unsigned long long *)(a.tab64 + m.table_off);
     const uint32_t lg = m.slots;
     const uint64_t smask = (1ull << lg) - 1ull;
     for (uint32_t i = threadIdx.x; i < un.count; i += 256) {
@@ -382,157 +495,213 @@ __global__ __launch_bounds__(256) void k_build_hbm(JoinArgs a, const Unit *build
     }
 }
 
-struct LdsTable {
-    typedef uint32_t slot_t;
-    uint32_t *t;
-    uint32_t  slots;
-    __device__ __forceinline__ uint32_t home(uint64_t h) const { return __umulhi((uint32_t)(h >> 32), slots); }
-    __device__ __forceinline__ uint32_t tag(uint64_t h) const { return (uint32_t)(h >> 16) & 0xffffu; }
-    __device__ __forceinline__ uint32_t next(uint32_t s) const { return s + 1 == slots ? 0 : s + 1; }
-    __device__ __forceinline__ bool probe(uint32_t s, uint32_t tg, bool &hit, uint32_t &pos) const
-    {
-        const uint32_t e = t[s];
-        const uint32_t et = e >> 16;
-        if (e == 0 || et < tg) return false;       // end of this key's run
-        hit = et == tg;
-        pos = (e & 0xffffu) - 1u;
-        return true;
-    }
-};
+__device__ __forceinline__ uint32_t t32_home(uint64_t h, uint32_t slots) { return __umulhi((uint32_t)(h >> 32), slots); }
+__device__ __forceinline__ uint32_t t32_tag(uint64_t h) { return (uint32_t)(h >> 16) & 0xffffu; }
 
-struct HbmTable {
-    typedef uint64_t slot_t;
-    const uint64_t *t;
-    uint32_t  lg;
-    __device__ __forceinline__ uint64_t home(uint64_t h) const { return h >> (64 - lg); }
-    __device__ __forceinline__ uint32_t tag(uint64_t h) const { return (uint32_t)h; }
-    __device__ __forceinline__ uint64_t next(uint64_t s) const { return (s + 1) & ((1ull << lg) - 1ull); }
-    __device__ __forceinline__ bool probe(uint64_t s, uint32_t tg, bool &hit, uint32_t &pos) const
-    {
-        const uint64_t e = t[s];
-        const uint32_t et = (uint32_t)(e >> 32);
-        if (e == 0 || et < tg) return false;
-        hit = et == tg;
-        pos = (uint32_t)e - 1u;
-        return true;
-    }
-};
-
-template <int BLOCK>
-__device__ __forceinline__ void lds_build(uint32_t *tbl, uint32_t slots, const rhj_tuple *bd, uint32_t bc)
+// 32-bit table: one workgroup per bucket builds it in LDS and dumps it to the arena.
+constexpr int BL_BLOCK = 1024;
+constexpr int BL_V = 4;
+__global__ __launch_bounds__(BL_BLOCK) void k_build_lds(JoinArgs a, const uint32_t *lds_buckets)
 {
-    for (uint32_t s = threadIdx.x; s < slots; s += BLOCK) tbl[s] = 0;
+    extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
+    if (blockIdx.x >= a.summary->lds_buckets) return;
+    const uint32_t b = lds_buckets[blockIdx.x];
+    const uint64_t cR = a.histR[b], cS = a.histS[b];
+    const bool flip = cR < cS;
+    const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
+    const uint32_t bc = (uint32_t)(flip ? cR : cS);
+    const BucketMeta m = a.meta[b];
+    const uint32_t slots = m.slots;
+    for (uint32_t s = threadIdx.x; s < slots; s += BL_BLOCK) tbl[s] = 0;
     __syncthreads();
-    LdsTable T{tbl, slots};
-    for (uint32_t i = threadIdx.x; i < bc; i += BLOCK) {
-        const uint64_t h = mix64(bd[i].value);
-        uint32_t s = T.home(h);
-        uint32_t v = (T.tag(h) << 16) | (i + 1u);
-        for (;;) {
-            const uint32_t old = atomicMax(&tbl[s], v);
-            if (old == 0) break;
-            if (old < v) v = old;
-            s = T.next(s);
+    for (uint32_t i0 = 0; i0 < bc; i0 += BL_BLOCK * BL_V) {
+        uint64_t key[BL_V];
+#pragma unroll
+        for (int k = 0; k < BL_V; ++k) {
+            const uint32_t i = i0 + k * BL_BLOCK + threadIdx.x;
+            key[k] = i < bc ? bd[i].value : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < BL_V; ++k) {
+            const uint32_t i = i0 + k * BL_BLOCK + threadIdx.x;
+            if (i >= bc) continue;
+            const uint64_t h = mix64(key[k]);
+            uint32_t s = t32_home(h, slots);
+            uint32_t v = (t32_tag(h) << 16) | (i + 1u);
+            for (;;) {
+                const uint32_t old = atomicMax(&tbl[s], v);
+                if (old == 0) break;
+                if (old < v) v = old;
+                s = s + 1 == slots ? 0 : s + 1;
+            }
         }
     }
     __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(a.tab32 + m.table_off);     // table_off and slots are multiples of 4
+    const uint4 *src = reinterpret_cast<const uint4 *>(tbl);
+    for (uint32_t s = threadIdx.x; s < slots / 4; s += BL_BLOCK) dst[s] = src[s];
 }
 
-// Probe one unit.  WRITE = false: count matches (first pass).  WRITE = true: emit
-// (row_idR,row_idS) pairs at unit_base[u] + running offset, in probe order and, per
-// probe tuple, in table-walk order = descending build position (rhjoin.c:227,240-246).
-template <int BLOCK, bool WRITE, class Table>
+struct Tab32 {
+    typedef uint32_t slot_t;
+    typedef uint32_t entry_t;
+    const uint32_t *t;
+    uint32_t  slots;
+    __device__ __forceinline__ slot_t home(uint64_t h) const { return t32_home(h, slots); }
+    __device__ __forceinline__ uint32_t tag(uint64_t h) const { return t32_tag(h); }
+    __device__ __forceinline__ slot_t next(slot_t s) const { return s + 1 == slots ? 0 : s + 1; }
+    __device__ __forceinline__ entry_t load(slot_t s) const { return t[s]; }
+    __device__ __forceinline__ bool live(entry_t e, uint32_t tg) const { return e != 0 && (e >> 16) >= tg; }
+    __device__ __forceinline__ bool hit(entry_t e, uint32_t tg) const { return (e >> 16) == tg; }
+    __device__ __forceinline__ uint32_t pos(entry_t e) const { return (e & 0xffffu) - 1u; }
+};
+
+struct Tab64 {
+    typedef uint64_t slot_t;
+    typedef uint64_t entry_t;
+    const uint64_t *t;
+    uint32_t  lg;
+    __device__ __forceinline__ slot_t home(uint64_t h) const { return h >> (64 - lg); }
+    __device__ __forceinline__ uint32_t tag(uint64_t h) const { return (uint32_t)h; }
+    __device__ __forceinline__ slot_t next(slot_t s) const { return (s + 1) & ((1ull << lg) - 1ull); }
+    __device__ __forceinline__ entry_t load(slot_t s) const { return t[s]; }
+    __device__ __forceinline__ bool live(entry_t e, uint32_t tg) const { return e != 0 && (uint32_t)(e >> 32) >= tg; }
+    __device__ __forceinline__ bool hit(entry_t e, uint32_t tg) const { return (uint32_t)(e >> 32) == tg; }
+    __device__ __forceinline__ uint32_t pos(entry_t e) const { return (uint32_t)e - 1u; }
+};
+
+// Probe one unit (<= PR_UNIT probe tuples, memory order (wave, round, lane)).
+// WRITE = false: count matches.  WRITE = true: emit (row_idR,row_idS) pairs at
+// unit_base[u] + offset, in probe order and, per probe tuple, in table-walk order =
+// descending build position (rhjoin.c:227,240-246).  All loads of one phase are
+// issued before the first is consumed: probe tuples, first table slots, candidates.
+template <bool WRITE, class Table>
 __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, const rhj_tuple *pr,
-                                           const rhj_tuple *bd, uint32_t count, bool flip, uint32_t u,
-                                           uint64_t *sm)
+                                           const rhj_tuple *bd, uint32_t count, bool flip, uint32_t u, uint32_t *wsum)
 {
-    uint64_t local = 0;                              // count pass: this thread's matches
-    uint64_t run = WRITE ? a.unit_base[u] : 0;       // write pass: next free output slot
-    for (uint32_t t0 = 0; t0 < count; t0 += BLOCK) {
-        const uint32_t i = t0 + threadIdx.x;
-        const bool ok = i < count;
-        uint64_t key = 0, prow = 0;
-        uint32_t c = 0;
-        uint64_t m0 = 0, m1 = 0;                     // row ids of the first two matches
-        typename Table::slot_t s0 = 0;
-        uint32_t tg = 0;
-        if (ok) {
-            const uint4 q = reinterpret_cast<const uint4 *>(pr)[i];
-            key = ((uint64_t)q.y << 32) | q.x;
-            prow = ((uint64_t)q.w << 32) | q.z;
-            const uint64_t h = mix64(key);
-            s0 = T.home(h);
-            tg = T.tag(h);
-            typename Table::slot_t s = s0;
-            for (;;) {
-                bool hit; uint32_t pos;
-                if (!T.probe(s, tg, hit, pos)) break;
-                if (hit) {
-                    if (WRITE) {
-                        const uint4 w = reinterpret_cast<const uint4 *>(bd)[pos];
-                        if (w.x == q.x && w.y == q.y) {
-                            const uint64_t brow = ((uint64_t)w.w << 32) | w.z;
-                            if (c == 0) m0 = brow; else if (c == 1) m1 = brow;
-                            ++c;
-                        }
-                    } else {
-                        c += bd[pos].value == key;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
+    const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
+    uint4 q[PR_V];
+    bool ok[PR_V];
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        const uint32_t i = w * (WAVE * PR_V) + k * WAVE + lane;
+        ok[k] = i < count;
+        if (ok[k]) q[k] = pr4[i];
+    }
+    typename Table::slot_t s0[PR_V];
+    typename Table::entry_t e0[PR_V];
+    uint32_t tg[PR_V];
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
+        s0[k] = T.home(h);
+        tg[k] = T.tag(h);
+        e0[k] = ok[k] ? T.load(s0[k]) : 0;
+    }
+    uint32_t nc[PR_V], p0[PR_V], p1[PR_V];           // tag-matching candidates (first two kept)
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        uint32_t c = 0, a0 = 0, a1 = 0;
+        typename Table::slot_t s = s0[k];
+        typename Table::entry_t e = e0[k];
+        while (T.live(e, tg[k])) {
+            if (T.hit(e, tg[k])) {
+                if (c == 0) a0 = T.pos(e); else if (c == 1) a1 = T.pos(e);
+                ++c;
+            }
+            s = T.next(s);
+            e = T.load(s);
+        }
+        nc[k] = c; p0[k] = a0; p1[k] = a1;
+    }
+    uint4 g0[PR_V], g1[PR_V];
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        if (nc[k] >= 1) g0[k] = bd4[p0[k]];
+        if (nc[k] >= 2) g1[k] = bd4[p1[k]];
+    }
+    uint32_t m[PR_V];                                 // verified matches per probe tuple
+    bool eq0[PR_V], eq1[PR_V];
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        eq0[k] = nc[k] >= 1 && g0[k].x == q[k].x && g0[k].y == q[k].y;
+        eq1[k] = nc[k] >= 2 && g1[k].x == q[k].x && g1[k].y == q[k].y;
+        m[k] = (uint32_t)eq0[k] + (uint32_t)eq1[k];
+        if (nc[k] > 2) {                              // long run of equal tags: verify every candidate
+            uint32_t c = 0;
+            typename Table::slot_t s = s0[k];
+            typename Table::entry_t e = e0[k];
+            while (T.live(e, tg[k])) {
+                if (T.hit(e, tg[k])) {
+                    const uint4 v = bd4[T.pos(e)];
+                    c += (v.x == q[k].x && v.y == q[k].y);
+                }
+                s = T.next(s);
+                e = T.load(s);
+            }
+            m[k] = c;
+        }
+    }
+    // offsets in (wave, round, lane) order
+    uint32_t off[PR_V], run = 0;
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        uint32_t tot;
+        off[k] = run + wave_excl_scan_u32(m[k], &tot);
+        run += tot;
+    }
+    if (lane == 0) wsum[w] = run;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < PR_BLOCK / WAVE; ++i) {
+        const uint32_t v = wsum[i];
+        if ((uint32_t)i < w) wbase += v;
+        total += v;
+    }
+    if (!WRITE) {
+        if (threadIdx.x == 0) a.unit_count[u] = total;
+        return;
+    }
+    const uint64_t base = a.unit_base[u] + wbase;
+    const uint64_t cap = a.out_capacity;
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+#pragma unroll
+    for (int k = 0; k < PR_V; ++k) {
+        if (m[k] == 0) continue;
+        uint64_t at = base + off[k];
+        const uint32_t prl = q[k].z, prh = q[k].w;      // probe row id
+        if (nc[k] <= 2) {
+            if (eq0[k]) {
+                if (at < cap) out[at] = flip ? make_uint4(g0[k].z, g0[k].w, prl, prh) : make_uint4(prl, prh, g0[k].z, g0[k].w);
+                ++at;
+            }
+            if (eq1[k] && at < cap)
+                out[at] = flip ? make_uint4(g1[k].z, g1[k].w, prl, prh) : make_uint4(prl, prh, g1[k].z, g1[k].w);
+        } else {
+            typename Table::slot_t s = s0[k];
+            typename Table::entry_t e = e0[k];
+            while (T.live(e, tg[k])) {
+                if (T.hit(e, tg[k])) {
+                    const uint4 v = bd4[T.pos(e)];
+                    if (v.x == q[k].x && v.y == q[k].y) {
+                        if (at < cap) out[at] = flip ? make_uint4(v.z, v.w, prl, prh) : make_uint4(prl, prh, v.z, v.w);
+                        ++at;
                     }
                 }
                 s = T.next(s);
+                e = T.load(s);
             }
         }
-        if (!WRITE) { local += c; continue; }
-
-        uint64_t tile_total;
-        const uint64_t off = run + block_excl_scan<BLOCK>((uint64_t)c, &tile_total, sm);
-        run += tile_total;
-        if (c) {
-            uint4 *out = reinterpret_cast<uint4 *>(a.out);
-            const uint64_t cap = a.out_capacity;
-            if (c <= 2) {
-                if (off < cap) {
-                    const uint64_t r = flip ? m0 : prow, s = flip ? prow : m0;
-                    out[off] = make_uint4((uint32_t)r, (uint32_t)(r >> 32), (uint32_t)s, (uint32_t)(s >> 32));
-                }
-                if (c == 2 && off + 1 < cap) {
-                    const uint64_t r = flip ? m1 : prow, s = flip ? prow : m1;
-                    out[off + 1] = make_uint4((uint32_t)r, (uint32_t)(r >> 32), (uint32_t)s, (uint32_t)(s >> 32));
-                }
-            } else {                                  // long duplicate run: walk again, emit as we go
-                uint64_t at = off;
-                typename Table::slot_t s = s0;
-                for (;;) {
-                    bool hit; uint32_t pos;
-                    if (!T.probe(s, tg, hit, pos)) break;
-                    if (hit) {
-                        const rhj_tuple w = bd[pos];
-                        if (w.value == key) {
-                            if (at < cap) {
-                                const uint64_t r = flip ? w.row_id : prow, sv = flip ? prow : w.row_id;
-                                out[at] = make_uint4((uint32_t)r, (uint32_t)(r >> 32), (uint32_t)sv, (uint32_t)(sv >> 32));
-                            }
-                            ++at;
-                        }
-                    }
-                    s = T.next(s);
-                }
-            }
-        }
-    }
-    if (!WRITE) {
-        uint64_t total;
-        block_excl_scan<BLOCK>(local, &total, sm);
-        if (threadIdx.x == 0) a.unit_count[u] = total;
     }
 }
 
-template <int BLOCK, bool WRITE>
-__global__ __launch_bounds__(BLOCK) void k_probe(JoinArgs a, uint32_t lds_slots_max)
+template <bool WRITE>
+__global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem);
-    uint64_t *sm = reinterpret_cast<uint64_t *>(smem + (((size_t)lds_slots_max * 4 + 15) & ~(size_t)15));
+    __shared__ uint32_t wsum[PR_BLOCK / WAVE];
     const uint32_t u = blockIdx.x;
     if (u >= a.summary->units) return;
     const Unit un = a.units[u];
@@ -541,15 +710,13 @@ __global__ __launch_bounds__(BLOCK) void k_probe(JoinArgs a, uint32_t lds_slots_
     const bool flip = cR < cS;                                         // S is streamed (r_s == 1)
     const rhj_tuple *pr = (flip ? a.partS + a.psumS[b] : a.partR + a.psumR[b]) + un.off;
     const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
-    const uint32_t bc = (uint32_t)(flip ? cR : cS);
     const BucketMeta m = a.meta[b];
     if (m.mode == 1) {
-        lds_build<BLOCK>(tbl, m.slots, bd, bc);
-        LdsTable T{tbl, m.slots};
-        probe_unit<BLOCK, WRITE>(a, T, pr, bd, un.count, flip, u, sm);
+        Tab32 T{a.tab32 + m.table_off, m.slots};
+        probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum);
     } else {
-        HbmTable T{a.tables + m.table_off, m.slots};
-        probe_unit<BLOCK, WRITE>(a, T, pr, bd, un.count, flip, u, sm);
+        Tab64 T{a.tab64 + m.table_off, m.slots};
+        probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum);
     }
 }
 
