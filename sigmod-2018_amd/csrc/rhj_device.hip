@@ -49,7 +49,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, tab32, tab64;
+        ucount, ubase, uflag, tab32, tab64;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
@@ -232,11 +232,11 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     const uint64_t nmin = nR < nS ? nR : nS;
     const uint64_t max_units = (uint64_t)bins + (nR + nS) / PR_UNIT + 2;
     const uint64_t max_bunits = (uint64_t)bins + nmin / build_chunk + 2;
-    const uint64_t max_tab32 = nmin + nmin / 2 + (uint64_t)72 * bins + 64;
+    const uint64_t max_tab32 = nmin + nmin / 2 + (uint64_t)80 * bins + 64;
     if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) ||
         ensure(g.ldsb, (size_t)bins * 4) || ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) ||
         ensure(g.summary, sizeof(PlanSummary)) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
-        ensure(g.tab32, max_tab32 * 4))
+        ensure(g.tab32, max_tab32 * 4) || ensure(g.uflag, max_units * 4))
         return -1;
     PlanArgs pa;
     pa.histR = ps.hist; pa.histS = ps.hist + bins;
@@ -259,6 +259,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     ja.summary = (const PlanSummary *)g.summary.p;
     ja.tab32 = (uint32_t *)g.tab32.p; ja.tab64 = nullptr;
     ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p;
+    ja.unit_flag = (uint32_t *)g.uflag.p;
     ja.out = nullptr; ja.out_capacity = 0;
 
     HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
@@ -273,9 +274,10 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         hipLaunchKernelGGL(k_build_lds, dim3((unsigned)plan.lds_buckets), dim3(BL_BLOCK), (size_t)plan.max_lds_slots * 4,
                            g.stream, ja, (const uint32_t *)g.ldsb.p);
 
+    const unsigned probe_grid = (unsigned)((plan.units + 7) / 8 * 8);
     HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
     if (plan.units)
-        hipLaunchKernelGGL((k_probe<false>), dim3((unsigned)plan.units), dim3(PR_BLOCK), 0, g.stream, ja);
+        hipLaunchKernelGGL((k_probe<false>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
     HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
                        (const uint64_t *)&((PlanSummary *)g.summary.p)->units, (uint64_t)0,
@@ -298,7 +300,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
     if (plan.units && M && out && out_capacity) {
         ja.out = out; ja.out_capacity = out_capacity;
-        hipLaunchKernelGGL((k_probe<true>), dim3((unsigned)plan.units), dim3(PR_BLOCK), 0, g.stream, ja);
+        hipLaunchKernelGGL((k_probe<true>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
     }
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     HIP_TRY(hipGetLastError());
@@ -445,7 +447,7 @@ void rhj_release(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);

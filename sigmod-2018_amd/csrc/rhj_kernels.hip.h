@@ -83,6 +83,7 @@ struct JoinArgs {
     uint32_t        *tab32;          // 32-bit table arena
     uint64_t        *tab64;          // 64-bit table arena
     uint64_t        *unit_count;     // [units] matches per unit (count pass)
+    uint32_t        *unit_flag;      // [units] 1 = a tag-matching candidate failed verification
     const uint64_t  *unit_base;      // [units] exclusive scan of unit_count
     rhj_result_tuple*out;
     uint64_t         out_capacity;
@@ -387,6 +388,8 @@ struct PlanArgs {
     uint32_t        pad;
 };
 
+constexpr uint32_t T32_PAD = 8;         // replica of the first 8 entries behind every 32-bit table
+
 __device__ __forceinline__ uint32_t lds_slots_for(uint64_t bc, uint32_t max_slots)
 {
     uint32_t s = (uint32_t)(bc + (bc >> 1)) + 4u;          // load factor <= 2/3 when it fits
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
         max_build = max(max_build, (uint32_t)min(bc, (uint64_t)0xffffffffu));
         if (bc <= a.lds_cap) {
             const uint32_t s = lds_slots_for(bc, a.lds_max_slots);
-            nlds += 1; slots32 += s;
+            nlds += 1; slots32 += s + T32_PAD;
             max_slots = max(max_slots, s);
         } else {
             nbu += (bc + a.build_chunk - 1) / a.build_chunk;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
                 m.slots = lds_slots_for(bc, a.lds_max_slots);
                 m.mode = 1;
                 m.table_off = s32base;
-                s32base += m.slots;
+                s32base += m.slots + T32_PAD;
                 a.lds_buckets[lbase++] = b;
             } else {
                 const uint32_t lg = 64 - __clzll((unsigned long long)(2 * bc - 1));
@@ -540,17 +543,29 @@ __global__ __launch_bounds__(BL_BLOCK) void k_build_lds(JoinArgs a, const uint32
     uint4 *dst = reinterpret_cast<uint4 *>(a.tab32 + m.table_off);     // table_off and slots are multiples of 4
     const uint4 *src = reinterpret_cast<const uint4 *>(tbl);
     for (uint32_t s = threadIdx.x; s < slots / 4; s += BL_BLOCK) dst[s] = src[s];
+    if (threadIdx.x < T32_PAD / 4) dst[slots / 4 + threadIdx.x] = src[threadIdx.x];   // wrap-free chunk reads
 }
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// 32-bit table in HBM.  The dump carries 8 padding entries (a replica of the first 8) so
+// a probe reads its home slot and the 7 after it with two 16-byte loads and no wrap.
 struct Tab32 {
     typedef uint32_t slot_t;
     typedef uint32_t entry_t;
+    static constexpr int CH = 8;
     const uint32_t *t;
     uint32_t  slots;
     __device__ __forceinline__ slot_t home(uint64_t h) const { return t32_home(h, slots); }
     __device__ __forceinline__ uint32_t tag(uint64_t h) const { return t32_tag(h); }
-    __device__ __forceinline__ slot_t next(slot_t s) const { return s + 1 == slots ? 0 : s + 1; }
+    __device__ __forceinline__ slot_t advance(slot_t s, uint32_t by) const { s += by; return s >= slots ? s - slots : s; }
     __device__ __forceinline__ entry_t load(slot_t s) const { return t[s]; }
+    __device__ __forceinline__ void load_chunk(slot_t s, entry_t (&e)[CH]) const
+    {
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4 *>(t + s);
+        const u32x4_a4 b = *reinterpret_cast<const u32x4_a4 *>(t + s + 4);
+        e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+    }
     __device__ __forceinline__ bool live(entry_t e, uint32_t tg) const { return e != 0 && (e >> 16) >= tg; }
     __device__ __forceinline__ bool hit(entry_t e, uint32_t tg) const { return (e >> 16) == tg; }
     __device__ __forceinline__ uint32_t pos(entry_t e) const { return (e & 0xffffu) - 1u; }
@@ -559,92 +574,158 @@ struct Tab32 {
 struct Tab64 {
     typedef uint64_t slot_t;
     typedef uint64_t entry_t;
+    static constexpr int CH = 4;
     const uint64_t *t;
     uint32_t  lg;
     __device__ __forceinline__ slot_t home(uint64_t h) const { return h >> (64 - lg); }
     __device__ __forceinline__ uint32_t tag(uint64_t h) const { return (uint32_t)h; }
-    __device__ __forceinline__ slot_t next(slot_t s) const { return (s + 1) & ((1ull << lg) - 1ull); }
+    __device__ __forceinline__ slot_t advance(slot_t s, uint32_t by) const { return (s + by) & ((1ull << lg) - 1ull); }
     __device__ __forceinline__ entry_t load(slot_t s) const { return t[s]; }
+    __device__ __forceinline__ void load_chunk(slot_t s, entry_t (&e)[CH]) const
+    {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) e[j] = t[advance(s, j)];
+    }
     __device__ __forceinline__ bool live(entry_t e, uint32_t tg) const { return e != 0 && (uint32_t)(e >> 32) >= tg; }
     __device__ __forceinline__ bool hit(entry_t e, uint32_t tg) const { return (uint32_t)(e >> 32) == tg; }
     __device__ __forceinline__ uint32_t pos(entry_t e) const { return (uint32_t)e - 1u; }
 };
 
+__device__ __forceinline__ uint4 make_pair(bool flip, uint32_t prl, uint32_t prh, uint32_t bl, uint32_t bh)
+{
+    return flip ? make_uint4(bl, bh, prl, prh) : make_uint4(prl, prh, bl, bh);
+}
+
 // Probe one unit (<= PR_UNIT probe tuples, memory order (wave, round, lane)).
-// WRITE = false: count matches.  WRITE = true: emit (row_idR,row_idS) pairs at
-// unit_base[u] + offset, in probe order and, per probe tuple, in table-walk order =
-// descending build position (rhjoin.c:227,240-246).  All loads of one phase are
-// issued before the first is consumed: probe tuples, first table slots, candidates.
+//
+// Count pass (WRITE = false): every tag-matching candidate is verified against the build
+// tuple's 64-bit key; the unit's verified match count goes to unit_count[u], and
+// unit_flag[u] records whether ANY candidate failed verification (a 16/32-bit tag
+// collision between different keys: rare).
+// Emit pass (WRITE = true): in a unit without such a collision every candidate is a
+// match, so the offsets follow from the candidate counts alone and the pairs are
+// written in one sweep (probe order; per probe tuple in table-walk order = descending
+// build position, rhjoin.c:227,240-246).  A flagged unit re-verifies while it emits.
+//
+// Loads are issued phase by phase before the first is consumed: probe tuples, one
+// 8-slot table chunk per tuple, then the candidates' build tuples.
 template <bool WRITE, class Table>
 __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, const rhj_tuple *pr,
                                            const rhj_tuple *bd, uint32_t count, bool flip, uint32_t u, uint32_t *wsum)
 {
+    constexpr int CH = Table::CH;
+    typedef typename Table::slot_t slot_t;
+    typedef typename Table::entry_t entry_t;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
     const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
+    const uint2 *bd2 = reinterpret_cast<const uint2 *>(bd);
+    const bool exact = WRITE ? a.unit_flag[u] != 0 : true;      // verify candidates?
+
     uint4 q[PR_V];
     bool ok[PR_V];
 #pragma unroll
     for (int k = 0; k < PR_V; ++k) {
         const uint32_t i = w * (WAVE * PR_V) + k * WAVE + lane;
         ok[k] = i < count;
-        if (ok[k]) q[k] = pr4[i];
+        q[k] = ok[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
     }
-    typename Table::slot_t s0[PR_V];
-    typename Table::entry_t e0[PR_V];
+    slot_t s0[PR_V];
     uint32_t tg[PR_V];
+    entry_t e[PR_V][CH];
 #pragma unroll
     for (int k = 0; k < PR_V; ++k) {
         const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
         s0[k] = T.home(h);
         tg[k] = T.tag(h);
-        e0[k] = ok[k] ? T.load(s0[k]) : 0;
-    }
-    uint32_t nc[PR_V], p0[PR_V], p1[PR_V];           // tag-matching candidates (first two kept)
+        if (ok[k]) T.load_chunk(s0[k], e[k]);
+        else {
 #pragma unroll
-    for (int k = 0; k < PR_V; ++k) {
-        uint32_t c = 0, a0 = 0, a1 = 0;
-        typename Table::slot_t s = s0[k];
-        typename Table::entry_t e = e0[k];
-        while (T.live(e, tg[k])) {
-            if (T.hit(e, tg[k])) {
-                if (c == 0) a0 = T.pos(e); else if (c == 1) a1 = T.pos(e);
-                ++c;
-            }
-            s = T.next(s);
-            e = T.load(s);
+            for (int j = 0; j < CH; ++j) e[k][j] = 0;
         }
-        nc[k] = c; p0[k] = a0; p1[k] = a1;
     }
-    uint4 g0[PR_V], g1[PR_V];
+    uint32_t hm[PR_V];                  // chunk entries that carry this key's tag
+    uint32_t p0[PR_V], p1[PR_V];        // build positions of the first two of them
+    bool more[PR_V];                    // the run continues past the chunk
 #pragma unroll
     for (int k = 0; k < PR_V; ++k) {
-        if (nc[k] >= 1) g0[k] = bd4[p0[k]];
-        if (nc[k] >= 2) g1[k] = bd4[p1[k]];
-    }
-    uint32_t m[PR_V];                                 // verified matches per probe tuple
-    bool eq0[PR_V], eq1[PR_V];
+        uint32_t mask = 0, a0 = 0, a1 = 0;
+        bool live = true;
 #pragma unroll
-    for (int k = 0; k < PR_V; ++k) {
-        eq0[k] = nc[k] >= 1 && g0[k].x == q[k].x && g0[k].y == q[k].y;
-        eq1[k] = nc[k] >= 2 && g1[k].x == q[k].x && g1[k].y == q[k].y;
-        m[k] = (uint32_t)eq0[k] + (uint32_t)eq1[k];
-        if (nc[k] > 2) {                              // long run of equal tags: verify every candidate
-            uint32_t c = 0;
-            typename Table::slot_t s = s0[k];
-            typename Table::entry_t e = e0[k];
-            while (T.live(e, tg[k])) {
-                if (T.hit(e, tg[k])) {
-                    const uint4 v = bd4[T.pos(e)];
-                    c += (v.x == q[k].x && v.y == q[k].y);
+        for (int j = 0; j < CH; ++j) {
+            live = live && T.live(e[k][j], tg[k]);
+            if (live && T.hit(e[k][j], tg[k])) {
+                if (mask == 0) a0 = T.pos(e[k][j]);
+                else if ((mask & (mask - 1)) == 0) a1 = T.pos(e[k][j]);
+                mask |= 1u << j;
+            }
+        }
+        hm[k] = mask; p0[k] = a0; p1[k] = a1;
+        more[k] = live;
+    }
+
+    // ---- matches per probe tuple
+    uint32_t m[PR_V];
+    bool fp = false;                    // a candidate failed verification (count pass)
+    if (!exact) {
+        // emit pass of a collision-free unit: candidates == matches
+#pragma unroll
+        for (int k = 0; k < PR_V; ++k) {
+            uint32_t c = (uint32_t)__popc(hm[k]);
+            if (more[k]) {
+                slot_t s = T.advance(s0[k], CH);
+                entry_t x = T.load(s);
+                while (T.live(x, tg[k])) { c += T.hit(x, tg[k]); s = T.advance(s, 1); x = T.load(s); }
+            }
+            m[k] = c;
+        }
+    } else {
+        // first two candidates of every tuple: gather all, then compare
+        uint2 g0[PR_V], g1[PR_V];
+        uint32_t rest[PR_V];
+#pragma unroll
+        for (int k = 0; k < PR_V; ++k) {
+            uint32_t r = hm[k];
+            g0[k] = make_uint2(0, 0); g1[k] = make_uint2(0, 0);
+            if (r) { r &= r - 1; g0[k] = bd2[2 * (size_t)p0[k]]; }
+            if (r) { r &= r - 1; g1[k] = bd2[2 * (size_t)p1[k]]; }
+            rest[k] = r;
+        }
+#pragma unroll
+        for (int k = 0; k < PR_V; ++k) {
+            const uint32_t nc = (uint32_t)__popc(hm[k]);
+            const bool eq0 = nc >= 1 && g0[k].x == q[k].x && g0[k].y == q[k].y;
+            const bool eq1 = nc >= 2 && g1[k].x == q[k].x && g1[k].y == q[k].y;
+            uint32_t c = (uint32_t)eq0 + (uint32_t)eq1;
+            fp = fp || (nc >= 1 && !eq0) || (nc >= 2 && !eq1);
+            if (rest[k]) {                                // third and later candidates of the chunk
+#pragma unroll
+                for (int j = 2; j < CH; ++j) {
+                    if ((rest[k] >> j) & 1u) {
+                        const uint2 v = bd2[2 * (size_t)T.pos(e[k][j])];
+                        const bool eq = v.x == q[k].x && v.y == q[k].y;
+                        c += eq; fp = fp || !eq;
+                    }
                 }
-                s = T.next(s);
-                e = T.load(s);
+            }
+            if (more[k]) {                                // run longer than the chunk
+                slot_t s = T.advance(s0[k], CH);
+                entry_t x = T.load(s);
+                while (T.live(x, tg[k])) {
+                    if (T.hit(x, tg[k])) {
+                        const uint2 v = bd2[2 * (size_t)T.pos(x)];
+                        const bool eq = v.x == q[k].x && v.y == q[k].y;
+                        c += eq; fp = fp || !eq;
+                    }
+                    s = T.advance(s, 1);
+                    x = T.load(s);
+                }
             }
             m[k] = c;
         }
     }
-    // offsets in (wave, round, lane) order
+
+    // ---- offsets in (wave, round, lane) order
     uint32_t off[PR_V], run = 0;
 #pragma unroll
     for (int k = 0; k < PR_V; ++k) {
@@ -653,6 +734,10 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
         run += tot;
     }
     if (lane == 0) wsum[w] = run;
+    if (!WRITE) {
+        const uint64_t any_fp = __ballot(fp);
+        if (lane == 0) wsum[PR_BLOCK / WAVE + w] = any_fp != 0;
+    }
     __syncthreads();
     uint32_t wbase = 0, total = 0;
 #pragma unroll
@@ -662,37 +747,80 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
         total += v;
     }
     if (!WRITE) {
-        if (threadIdx.x == 0) a.unit_count[u] = total;
+        if (threadIdx.x == 0) {
+            uint32_t f = 0;
+#pragma unroll
+            for (int i = 0; i < PR_BLOCK / WAVE; ++i) f |= wsum[PR_BLOCK / WAVE + i];
+            a.unit_count[u] = total;
+            a.unit_flag[u] = f;
+        }
         return;
     }
+
+    // ---- emit
     const uint64_t base = a.unit_base[u] + wbase;
     const uint64_t cap = a.out_capacity;
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    if (!exact) {
+        // first candidate of every tuple in one batch of gathers, the rest in a loop
+        uint2 r0[PR_V];
+        uint32_t rest[PR_V];
 #pragma unroll
-    for (int k = 0; k < PR_V; ++k) {
-        if (m[k] == 0) continue;
-        uint64_t at = base + off[k];
-        const uint32_t prl = q[k].z, prh = q[k].w;      // probe row id
-        if (nc[k] <= 2) {
-            if (eq0[k]) {
-                if (at < cap) out[at] = flip ? make_uint4(g0[k].z, g0[k].w, prl, prh) : make_uint4(prl, prh, g0[k].z, g0[k].w);
-                ++at;
-            }
-            if (eq1[k] && at < cap)
-                out[at] = flip ? make_uint4(g1[k].z, g1[k].w, prl, prh) : make_uint4(prl, prh, g1[k].z, g1[k].w);
-        } else {
-            typename Table::slot_t s = s0[k];
-            typename Table::entry_t e = e0[k];
-            while (T.live(e, tg[k])) {
-                if (T.hit(e, tg[k])) {
-                    const uint4 v = bd4[T.pos(e)];
-                    if (v.x == q[k].x && v.y == q[k].y) {
-                        if (at < cap) out[at] = flip ? make_uint4(v.z, v.w, prl, prh) : make_uint4(prl, prh, v.z, v.w);
+        for (int k = 0; k < PR_V; ++k) {
+            uint32_t r = hm[k];
+            r0[k] = make_uint2(0, 0);
+            if (r) { r &= r - 1; r0[k] = bd2[2 * (size_t)p0[k] + 1]; }
+            rest[k] = r;
+        }
+#pragma unroll
+        for (int k = 0; k < PR_V; ++k) {
+            if (m[k] == 0) continue;
+            uint64_t at = base + off[k];
+            const uint32_t prl = q[k].z, prh = q[k].w;
+            if (hm[k]) { if (at < cap) out[at] = make_pair(flip, prl, prh, r0[k].x, r0[k].y); ++at; }
+            if (rest[k]) {
+#pragma unroll
+                for (int j = 1; j < CH; ++j) {
+                    if ((rest[k] >> j) & 1u) {
+                        const uint2 v = bd2[2 * (size_t)T.pos(e[k][j]) + 1];
+                        if (at < cap) out[at] = make_pair(flip, prl, prh, v.x, v.y);
                         ++at;
                     }
                 }
-                s = T.next(s);
-                e = T.load(s);
+            }
+            if (more[k]) {
+                slot_t s = T.advance(s0[k], CH);
+                entry_t x = T.load(s);
+                while (T.live(x, tg[k])) {
+                    if (T.hit(x, tg[k])) {
+                        const uint2 v = bd2[2 * (size_t)T.pos(x) + 1];
+                        if (at < cap) out[at] = make_pair(flip, prl, prh, v.x, v.y);
+                        ++at;
+                    }
+                    s = T.advance(s, 1);
+                    x = T.load(s);
+                }
+            }
+        }
+    } else {
+        // flagged unit: verify every candidate again while emitting
+#pragma unroll
+        for (int k = 0; k < PR_V; ++k) {
+            if (m[k] == 0) continue;
+            uint64_t at = base + off[k];
+            const uint32_t prl = q[k].z, prh = q[k].w;
+            slot_t s = s0[k];
+            entry_t x = T.load(s);
+            while (T.live(x, tg[k])) {
+                if (T.hit(x, tg[k])) {
+                    const uint4 v = bd4[T.pos(x)];
+                    if (v.x == q[k].x && v.y == q[k].y) {
+                        if (at < cap) out[at] = make_pair(flip, prl, prh, v.z, v.w);
+                        ++at;
+                    }
+                }
+                s = T.advance(s, 1);
+                x = T.load(s);
             }
         }
     }
@@ -701,9 +829,14 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
 template <bool WRITE>
 __global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
 {
-    __shared__ uint32_t wsum[PR_BLOCK / WAVE];
-    const uint32_t u = blockIdx.x;
-    if (u >= a.summary->units) return;
+    __shared__ uint32_t wsum[2 * PR_BLOCK / WAVE];
+    // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so
+    // give XCD x the x-th contiguous eighth of the canonical unit list; the tables and
+    // build sides an XCD's L2 has to hold are then those of a handful of adjacent buckets.
+    const uint32_t nu = (uint32_t)a.summary->units;
+    const uint32_t per = (nu + 7u) / 8u;
+    const uint32_t u = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || u >= nu) return;
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
     const uint64_t cR = a.histR[b], cS = a.histS[b];
