@@ -135,7 +135,15 @@ void rhj_set_node_pairs(uint64_t pairs_per_node);
 int  rhj_set_device(int ordinal);
 /* Launch all work on this hipStream_t (passed as void*); NULL = own stream. */
 void rhj_set_stream(void *hip_stream);
-/* Force the HBM-table probe path even for buckets whose table fits LDS. */
+/* Path selection (results are identical on every path; tests run all three):
+ *   fused (default)  one workgroup per bucket keeps its tag table in LDS, builds, probes and
+ *                    emits in one kernel; chosen when every bucket's build side fits LDS;
+ *   tiled            tag tables in HBM, tile-granular probe units, count + emit kernels;
+ *                    taken automatically when some bucket is too large for LDS, or with
+ *                    rhj_set_fused(0) / env RHJ_NO_FUSED=1;
+ *   rhj_set_force_hbm_table(1) additionally builds every table with global atomics
+ *                    (64-bit entries), the path of buckets beyond 65534 build tuples. */
+void rhj_set_fused(int on);
 void rhj_set_force_hbm_table(int on);
 
 /* ---- device-resident entry points (what RadixHashJoin()/Filter() call

@@ -45,11 +45,13 @@ struct Ctx {
     int         bits = 4;
     int         null_on_empty = 0;
     int         force_hbm = 0;
+    int         ablate = 0;
+    int         no_fused = 0;
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
@@ -67,6 +69,8 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 12) g.bits = b; }
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
+        if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);
+        if ((e = getenv("RHJ_NO_FUSED"))) g.no_fused = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
     }
 } env_defaults;
@@ -95,6 +99,8 @@ int ctx_init()
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
     // dynamic LDS above 64 KiB has to be requested per kernel
     HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     g.ready = true;
     return 0;
@@ -225,8 +231,10 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
 
     // ---- plan
     const uint32_t build_chunk = 4096;
-    const uint32_t lds_max_slots = LDS_BUDGET / 4;                         // whole LDS holds one 32-bit table
+    const bool want_fused = !g.no_fused && !g.force_hbm;
+    const uint32_t lds_max_slots = LDS_BUDGET / 4 / 4 * 4;                 // tiled path: k_build_lds owns the whole LDS
     uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
+    if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 64) / 6;        // fused: 4 B node + 2 B head link per build tuple
     if (lds_cap > 65534) lds_cap = 65534;                                  // 16-bit position + 1
     if (g.force_hbm) lds_cap = 0;
     const uint64_t nmin = nR < nS ? nR : nS;
@@ -236,19 +244,28 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) ||
         ensure(g.ldsb, (size_t)bins * 4) || ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) ||
         ensure(g.summary, sizeof(PlanSummary)) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
-        ensure(g.tab32, max_tab32 * 4) || ensure(g.uflag, max_units * 4))
+        ensure(g.uflag, max_units * 4))
         return -1;
     PlanArgs pa;
     pa.histR = ps.hist; pa.histS = ps.hist + bins;
     pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
-    pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk; pa.pad = 0;
+    pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk;
+    pa.span_lds = want_fused ? FJ_SPAN : PR_UNIT;
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     PlanSummary *hs = (PlanSummary *)g.pin;
     HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #1: launch geometry
-    const PlanSummary plan = *hs;
+    PlanSummary plan = *hs;
+    bool fused = want_fused && plan.build_units == 0;         // every bucket's table fits LDS
+    if (want_fused && !fused) {                               // some bucket needs an HBM table: tiled path for all
+        pa.span_lds = PR_UNIT;
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+        HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        plan = *hs;
+    }
     st.units = plan.units; st.hbm_units = plan.build_units; st.max_build = plan.max_build;
     st.table_slots = plan.hbm_slots + plan.tab32_slots;
 
@@ -257,11 +274,72 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     ja.histR = ps.hist; ja.histS = ps.hist + bins; ja.psumR = ps.psum; ja.psumS = ps.psum + bins;
     ja.units = (const Unit *)g.units.p; ja.meta = (const BucketMeta *)g.meta.p;
     ja.summary = (const PlanSummary *)g.summary.p;
-    ja.tab32 = (uint32_t *)g.tab32.p; ja.tab64 = nullptr;
+    ja.tab32 = nullptr; ja.tab64 = nullptr;
     ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p;
     ja.unit_flag = (uint32_t *)g.uflag.p;
     ja.out = nullptr; ja.out_capacity = 0;
+    ja.ablate = (uint32_t)g.ablate; ja.pad = 0;
 
+    if (fused) {
+        // ---- fused LDS path: build + probe + emit in one kernel, chained output offsets
+        if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
+            ensure(g.status, (plan.units + 1) * 8 + 64))
+            return -1;
+        FusedArgs fa;
+        fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
+        fa.status = (uint64_t *)g.status.p + 8;               // words 0..7 hold the ticket
+        fa.ticket = (uint32_t *)g.status.p;
+        fa.nR = nR;
+        fa.dbg = nullptr;
+        if (getenv("RHJ_STAMPS")) {                           // diagnostic runs only
+            if (ensure(g.dbg, (plan.units + 1) * 64)) return -1;
+            fa.dbg = (uint64_t *)g.dbg.p;
+        }
+        uint64_t M = 0;
+        const uint64_t mb = plan.max_build < 64 ? 64 : plan.max_build;
+        const size_t fused_lds = (((size_t)mb + 3) & ~(size_t)3) * 4 + (mb + 1) / 2 * 4 + 16;
+        if (use_ctx_out) {
+            const uint64_t guess = (nR > nS ? nR : nS) + 1024;
+            if (g.out.cap < guess * sizeof(rhj_result_tuple) && ensure(g.out, guess * sizeof(rhj_result_tuple))) return -1;
+            out = (rhj_result_tuple *)g.out.p;
+            out_capacity = g.out.cap / sizeof(rhj_result_tuple);
+        }
+        HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
+        HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
+        HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
+        HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            ja.out = out; ja.out_capacity = out ? out_capacity : 0;
+            fa.j = ja;
+            HIP_TRY(hipMemsetAsync(g.status.p, 0, (plan.units + 1) * 8 + 64, g.stream));
+            if (plan.units)
+                hipLaunchKernelGGL(k_join_fused, dim3((unsigned)plan.units), dim3(FJ_BLOCK), fused_lds, g.stream, fa);
+            hipLaunchKernelGGL(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
+                               (const PlanSummary *)g.summary.p, &((PlanSummary *)g.summary.p)->matches);
+            HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+            HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            M = hs->matches;
+            if (!use_ctx_out || M <= out_capacity) break;
+            if (ensure(g.out, M * sizeof(rhj_result_tuple))) return -1;    // rare: fan-out above the guess
+            out = (rhj_result_tuple *)g.out.p;
+            out_capacity = M;
+        }
+        *matches = M;
+        st.matches = M;
+        if (ctx_out) *ctx_out = out;
+        st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
+        st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
+        st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
+        st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
+        st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
+        st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+        return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
+    }
+
+    if (ensure(g.tab32, max_tab32 * 4)) return -1;
+    ja.tab32 = (uint32_t *)g.tab32.p;
     HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
     if (plan.hbm_slots) {
         if (ensure(g.tab64, plan.hbm_slots * 8)) return -1;
@@ -375,6 +453,13 @@ int rhj_get_radix_bits(void) { return g.bits; }
 void rhj_set_empty_mode(int null_on_empty) { g.null_on_empty = null_on_empty; }
 void rhj_set_node_pairs(uint64_t pairs) { g.node_pairs = pairs; }
 void rhj_set_force_hbm_table(int on) { g.force_hbm = on; }
+void rhj_set_fused(int on) { g.no_fused = !on; }
+/* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */
+int rhj_debug_stamps(uint64_t *host, uint64_t units)
+{
+    if (!g.dbg.p) return -1;
+    return hipMemcpy(host, g.dbg.p, units * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 int rhj_set_device(int ordinal)
 {
     if (g.ready) return -1;
@@ -447,7 +532,7 @@ void rhj_release(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);

@@ -87,6 +87,8 @@ struct JoinArgs {
     const uint64_t  *unit_base;      // [units] exclusive scan of unit_count
     rhj_result_tuple*out;
     uint64_t         out_capacity;
+    uint32_t         ablate;         // timing experiments only (RHJ_ABLATE): 1 no gathers, 2 no table reads
+    uint32_t         pad;
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
@@ -385,7 +387,7 @@ struct PlanArgs {
     uint32_t        lds_cap;        // largest build side served by an LDS-built table
     uint32_t        lds_max_slots;  // LDS slot budget
     uint32_t        build_chunk;    // build tuples per 64-bit-table build unit
-    uint32_t        pad;
+    uint32_t        span_lds;       // probe tuples per unit in LDS-table buckets (PR_UNIT on the tiled path)
 };
 
 constexpr uint32_t T32_PAD = 8;         // replica of the first 8 entries behind every 32-bit table
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
         const uint64_t cR = a.histR[b], cS = a.histS[b];
         if (cR == 0 || cS == 0) continue;
         const uint64_t pc = cR >= cS ? cR : cS, bc = cR >= cS ? cS : cR;   // rhjoin.c:86 (>=)
-        nu += (pc + PR_UNIT - 1) / PR_UNIT;
+        const uint64_t span = bc <= a.lds_cap ? a.span_lds : PR_UNIT;
+        nu += (pc + span - 1) / span;
         max_build = max(max_build, (uint32_t)min(bc, (uint64_t)0xffffffffu));
         if (bc <= a.lds_cap) {
             const uint32_t s = lds_slots_for(bc, a.lds_max_slots);
@@ -454,8 +457,9 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
                     a.build_units[bbase++] = u;
                 }
             }
-            for (uint64_t o = 0; o < pc; o += PR_UNIT) {
-                Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min((uint64_t)PR_UNIT, pc - o);
+            const uint64_t span = bc <= a.lds_cap ? a.span_lds : PR_UNIT;
+            for (uint64_t o = 0; o < pc; o += span) {
+                Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min(span, pc - o);
                 a.units[ubase++] = u;
             }
         }
@@ -546,10 +550,10 @@ __global__ __launch_bounds__(BL_BLOCK) void k_build_lds(JoinArgs a, const uint32
     if (threadIdx.x < T32_PAD / 4) dst[slots / 4 + threadIdx.x] = src[threadIdx.x];   // wrap-free chunk reads
 }
 
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-
-// 32-bit table in HBM.  The dump carries 8 padding entries (a replica of the first 8) so
-// a probe reads its home slot and the 7 after it with two 16-byte loads and no wrap.
+// 32-bit table in HBM.  A probe reads the two 16-byte-aligned groups of four entries from
+// the one that holds its home slot (unaligned 16-byte loads are split by the texture
+// addresser and measured ~4x its cycles); entries in front of the home slot are skipped.
+// The dump carries 8 padding entries (a replica of the first 8) so no read wraps.
 struct Tab32 {
     typedef uint32_t slot_t;
     typedef uint32_t entry_t;
@@ -560,10 +564,11 @@ struct Tab32 {
     __device__ __forceinline__ uint32_t tag(uint64_t h) const { return t32_tag(h); }
     __device__ __forceinline__ slot_t advance(slot_t s, uint32_t by) const { s += by; return s >= slots ? s - slots : s; }
     __device__ __forceinline__ entry_t load(slot_t s) const { return t[s]; }
+    __device__ __forceinline__ uint32_t skip(slot_t s) const { return s & 3u; }
     __device__ __forceinline__ void load_chunk(slot_t s, entry_t (&e)[CH]) const
     {
-        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4 *>(t + s);
-        const u32x4_a4 b = *reinterpret_cast<const u32x4_a4 *>(t + s + 4);
+        const uint4 *g = reinterpret_cast<const uint4 *>(t + (s & ~3u));
+        const uint4 a = g[0], b = g[1];
         e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
     }
     __device__ __forceinline__ bool live(entry_t e, uint32_t tg) const { return e != 0 && (e >> 16) >= tg; }
@@ -581,6 +586,7 @@ struct Tab64 {
     __device__ __forceinline__ uint32_t tag(uint64_t h) const { return (uint32_t)h; }
     __device__ __forceinline__ slot_t advance(slot_t s, uint32_t by) const { return (s + by) & ((1ull << lg) - 1ull); }
     __device__ __forceinline__ entry_t load(slot_t s) const { return t[s]; }
+    __device__ __forceinline__ uint32_t skip(slot_t) const { return 0; }
     __device__ __forceinline__ void load_chunk(slot_t s, entry_t (&e)[CH]) const
     {
 #pragma unroll
@@ -620,7 +626,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
     const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
     const uint2 *bd2 = reinterpret_cast<const uint2 *>(bd);
-    const bool exact = WRITE ? a.unit_flag[u] != 0 : true;      // verify candidates?
+    const bool exact = WRITE ? a.unit_flag[u] != 0 : a.ablate == 0;      // verify candidates?
 
     uint4 q[PR_V];
     bool ok[PR_V];
@@ -638,7 +644,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
         const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
         s0[k] = T.home(h);
         tg[k] = T.tag(h);
-        if (ok[k]) T.load_chunk(s0[k], e[k]);
+        if (ok[k] && a.ablate != 2) T.load_chunk(s0[k], e[k]);
         else {
 #pragma unroll
             for (int j = 0; j < CH; ++j) e[k][j] = 0;
@@ -651,10 +657,12 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
     for (int k = 0; k < PR_V; ++k) {
         uint32_t mask = 0, a0 = 0, a1 = 0;
         bool live = true;
+        const uint32_t sk = T.skip(s0[k]);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            live = live && T.live(e[k][j], tg[k]);
-            if (live && T.hit(e[k][j], tg[k])) {
+            const bool in = (uint32_t)j >= sk;               // at or behind the home slot
+            live = live && (!in || T.live(e[k][j], tg[k]));
+            if (in && live && T.hit(e[k][j], tg[k])) {
                 if (mask == 0) a0 = T.pos(e[k][j]);
                 else if ((mask & (mask - 1)) == 0) a1 = T.pos(e[k][j]);
                 mask |= 1u << j;
@@ -673,7 +681,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
         for (int k = 0; k < PR_V; ++k) {
             uint32_t c = (uint32_t)__popc(hm[k]);
             if (more[k]) {
-                slot_t s = T.advance(s0[k], CH);
+                slot_t s = T.advance(s0[k], CH - T.skip(s0[k]));
                 entry_t x = T.load(s);
                 while (T.live(x, tg[k])) { c += T.hit(x, tg[k]); s = T.advance(s, 1); x = T.load(s); }
             }
@@ -700,7 +708,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
             fp = fp || (nc >= 1 && !eq0) || (nc >= 2 && !eq1);
             if (rest[k]) {                                // third and later candidates of the chunk
 #pragma unroll
-                for (int j = 2; j < CH; ++j) {
+                for (int j = 0; j < CH; ++j) {
                     if ((rest[k] >> j) & 1u) {
                         const uint2 v = bd2[2 * (size_t)T.pos(e[k][j])];
                         const bool eq = v.x == q[k].x && v.y == q[k].y;
@@ -709,7 +717,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
                 }
             }
             if (more[k]) {                                // run longer than the chunk
-                slot_t s = T.advance(s0[k], CH);
+                slot_t s = T.advance(s0[k], CH - T.skip(s0[k]));
                 entry_t x = T.load(s);
                 while (T.live(x, tg[k])) {
                     if (T.hit(x, tg[k])) {
@@ -780,7 +788,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
             if (hm[k]) { if (at < cap) out[at] = make_pair(flip, prl, prh, r0[k].x, r0[k].y); ++at; }
             if (rest[k]) {
 #pragma unroll
-                for (int j = 1; j < CH; ++j) {
+                for (int j = 0; j < CH; ++j) {
                     if ((rest[k] >> j) & 1u) {
                         const uint2 v = bd2[2 * (size_t)T.pos(e[k][j]) + 1];
                         if (at < cap) out[at] = make_pair(flip, prl, prh, v.x, v.y);
@@ -789,7 +797,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
                 }
             }
             if (more[k]) {
-                slot_t s = T.advance(s0[k], CH);
+                slot_t s = T.advance(s0[k], CH - T.skip(s0[k]));
                 entry_t x = T.load(s);
                 while (T.live(x, tg[k])) {
                     if (T.hit(x, tg[k])) {
@@ -851,6 +859,358 @@ __global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
         Tab64 T{a.tab64 + m.table_off, m.slots};
         probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum);
     }
+}
+
+// ------------------------------------------------------------- fused LDS join
+//
+// One workgroup per unit = (bucket, up to FJ_SPAN probe tuples), taken in canonical order
+// through a ticket so that a unit's predecessors are always running or done.
+//   build    ordered 32-bit table of the bucket's build side in LDS
+//   phase 1  stream the unit's probe tuples; table walk in LDS; ONE global gather per
+//            candidate (key to verify + row id); per probe tuple stash the match count
+//            (u8) and the first match's build row id (u64), coalesced
+//   chain    publish the unit's match total, decoupled look-back over the predecessors
+//            (one 8-byte {flag,value} word per unit, agent-scope relaxed atomics)
+//   phase 2  stream probe row ids + stash and write the pairs at their final canonical
+//            positions; only tuples with two or more matches walk the table again
+// Random global accesses per probe tuple: one 128-byte line (the gather); everything
+// else is streaming or LDS.
+constexpr int FJ_BLOCK = 1024;
+constexpr int FJ_WAVES = FJ_BLOCK / WAVE;
+constexpr int FJ_V = 4;
+constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
+constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
+constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
+
+struct FusedArgs {
+    JoinArgs  j;
+    uint8_t  *stash_cnt;      // [nR + nS] matches per probe tuple, saturating at 255
+    uint64_t *stash_row;      // [nR + nS] build row id of the first match
+    uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
+    uint32_t *ticket;
+    uint64_t  nR;
+    uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
+};
+
+
+// LDS index of the fused kernel: sorted chains.
+//   node[i]  (i = build position in the bucket)  = tag16 << 16 | next   (next = position + 1, 0 = end)
+//   head16[] one 16-bit link per hash slot (two per 32-bit word), slots = build count
+// A chain lists the build positions that hash to its slot in DESCENDING order — exactly the
+// reference's bucket/chain index (CreateIndex walks last->first and appends at the tail,
+// rhjoin.c:219-250) — built here by lock-free sorted insertion (32-bit CAS on the word that
+// holds the 16-bit link), so the structure is the same for every interleaving.  Unlike
+// linear probing there is no clustering: a walk is as long as its chain (Poisson, max ~7 at
+// load 1), and the FJ_V tuples of a lane walk their chains in lockstep.
+struct FjIndex {
+    uint32_t *node;      // [bc]
+    uint32_t *headw;     // [(hs + 1) / 2] two 16-bit links per word
+    uint32_t  hs;
+    __device__ __forceinline__ uint32_t slot(uint64_t h) const { return __umulhi((uint32_t)(h >> 32), hs); }
+    __device__ __forceinline__ uint32_t head(uint32_t sl) const
+    {
+        const uint32_t wv = headw[sl >> 1];
+        return (sl & 1u) ? wv >> 16 : wv & 0xffffu;
+    }
+};
+
+__device__ __forceinline__ void fj_insert(const FjIndex &X, uint64_t key, uint32_t i)
+{
+    const uint64_t h = mix64(key);
+    const uint32_t sl = X.slot(h);
+    const uint32_t tagw = t32_tag(h) << 16;
+    bool at_head = true;
+    uint32_t prev = 0;                                   // node index when !at_head
+    for (;;) {
+        uint32_t word, cur;
+        if (at_head) { word = X.headw[sl >> 1]; cur = (sl & 1u) ? word >> 16 : word & 0xffffu; }
+        else         { word = X.node[prev];     cur = word & 0xffffu; }
+        if (cur != 0 && cur - 1u > i) { at_head = false; prev = cur - 1u; continue; }   // keep descending order
+        X.node[i] = tagw | cur;                          // complete before it becomes reachable
+        uint32_t want;
+        if (at_head) want = (sl & 1u) ? (word & 0xffffu) | ((i + 1u) << 16) : (word & 0xffff0000u) | (i + 1u);
+        else         want = (word & 0xffff0000u) | (i + 1u);
+        uint32_t *addr = at_head ? &X.headw[sl >> 1] : &X.node[prev];
+        if (atomicCAS(addr, word, want) == word) break;  // else: the link (or its word neighbour) moved, look again
+    }
+}
+
+// One round of the probe walk: every tuple with a live cursor follows its chain to the next
+// node that carries its tag (pos[k]) or to the end (cursor 0).  Returns whether any lane of
+// the wave found a candidate.
+__device__ __forceinline__ bool fj_walk_round(const FjIndex &X, uint32_t (&cur)[FJ_V], const uint32_t (&tg)[FJ_V],
+                                              uint32_t (&pos)[FJ_V])
+{
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) pos[k] = 0xffffffffu;
+    for (;;) {
+        uint32_t n[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k)
+            n[k] = (cur[k] != 0 && pos[k] == 0xffffffffu) ? X.node[cur[k] - 1u] : 0;
+        bool again = false;
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            if (cur[k] != 0 && pos[k] == 0xffffffffu) {
+                if ((n[k] >> 16) == tg[k]) { pos[k] = cur[k] - 1u; found = true; }
+                cur[k] = n[k] & 0xffffu;
+                again = again || (pos[k] == 0xffffffffu && cur[k] != 0);
+            }
+        }
+        if (__ballot(again) == 0) break;
+    }
+    return __ballot(found) != 0;
+}
+
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
+    __shared__ uint32_t sh_u;
+    __shared__ uint64_t sh_base;
+    __shared__ uint32_t wsum[FJ_WAVES];
+    const JoinArgs &a = f.j;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+
+    if (threadIdx.x == 0) sh_u = atomicAdd(f.ticket, 1u);
+    __syncthreads();
+    const uint32_t u = sh_u;
+    if (u >= a.summary->units) return;
+    const Unit un = a.units[u];
+    const uint32_t b = un.bucket;
+    const uint64_t cR = a.histR[b], cS = a.histS[b];
+    const bool flip = cR < cS;                                         // S is streamed (r_s == 1)
+    const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;   // position in the probe relation
+    const rhj_tuple *pr = (flip ? a.partS : a.partR) + ppos;
+    const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
+    const uint32_t bc = (uint32_t)(flip ? cR : cS);
+    FjIndex X;
+    X.node = tbl;
+    X.hs = bc < 64u ? 64u : bc;
+    X.headw = tbl + ((bc + 3u) & ~3u);
+    uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
+    uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
+    const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
+    const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
+
+    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    // ---- build
+    for (uint32_t sidx = threadIdx.x; sidx < (X.hs + 1u) / 2u; sidx += FJ_BLOCK) X.headw[sidx] = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
+        uint64_t key[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = i0 + k * FJ_BLOCK + threadIdx.x;
+            key[k] = i < bc ? bd[i].value : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = i0 + k * FJ_BLOCK + threadIdx.x;
+            if (i < bc) fj_insert(X, key[k], i);
+        }
+    }
+    __syncthreads();
+    if (a.ablate == 1) return;                        // timing experiment: build only
+    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- phase 1: count + stash.  Candidates are taken in lockstep rounds: every round
+    // walks each tuple's table run (LDS) to its next tag hit and issues the gathers of all
+    // of them together, so a batch costs max-multiplicity round trips, not one per candidate.
+    uint32_t mine = 0;
+    uint64_t acc_load = 0, acc_walk = 0, acc_gather = 0, acc_stash = 0, tA = 0;
+#define FJ_STAMP(accum)                                                                 \
+    if (f.dbg) {                                                                        \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                     \
+        const uint64_t now_ = __builtin_amdgcn_s_memrealtime();                         \
+        accum += now_ - tA; tA = now_;                                                  \
+    }
+    for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
+        uint4 q[FJ_V];
+        uint32_t cur[FJ_V], tg[FJ_V];
+        uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
+        if (f.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tA = __builtin_amdgcn_s_memrealtime(); }
+        bool okk[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
+            okk[k] = i < un.count;
+            q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
+            tg[k] = t32_tag(h);
+            cur[k] = okk[k] ? X.head(X.slot(h)) : 0;
+            c[k] = 0; flo[k] = 0; fhi[k] = 0;
+        }
+        FJ_STAMP(acc_load)
+        for (;;) {
+            uint32_t pos[FJ_V];
+            const bool any = fj_walk_round(X, cur, tg, pos);
+            FJ_STAMP(acc_walk)
+            if (!any) break;
+            uint4 g[FJ_V];
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k)
+                g[k] = (pos[k] != 0xffffffffu && a.ablate != 2) ? bd4[pos[k]] : q[k];
+            FJ_STAMP(acc_gather)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
+                if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
+                c[k] += eq;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
+            if (i < un.count && a.ablate != 4) {
+                scnt[i] = (uint8_t)min(c[k], 255u);
+                reinterpret_cast<uint2 *>(srow)[i] = make_uint2(flo[k], fhi[k]);
+            }
+            mine += c[k];
+        }
+        FJ_STAMP(acc_stash)
+    }
+    if (f.dbg && threadIdx.x == 64) {       // wave 1's view
+        f.dbg[(size_t)u * 8 + 6] = (acc_load << 32) | acc_walk;
+        f.dbg[(size_t)u * 8 + 7] = (acc_gather << 32) | acc_stash;
+    }
+
+    // ---- unit total -> chained scan
+    if (f.dbg && lane == 0) { if (w == 0) f.dbg[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); if (w == FJ_WAVES - 1) f.dbg[(size_t)u * 8 + 5] = __builtin_amdgcn_s_memrealtime(); }
+    {
+        uint32_t tot;
+        wave_excl_scan_u32(mine, &tot);
+        if (lane == 0) wsum[w] = tot;
+    }
+    __syncthreads();
+    if (w == 0) {
+        uint64_t total = 0;
+        for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
+        unsigned long long *st = (unsigned long long *)f.status;
+        uint64_t excl = 0;
+        if (u == 0) {
+            if (lane == 0) __hip_atomic_store(&st[0], (2ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&st[u], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t j = (int64_t)u - 1;               // look back 64 predecessors at a time
+            for (;;) {
+                const int64_t idx = j - lane;
+                unsigned long long v = 2ull << 62;    // virtual "prefix 0" in front of unit 0
+                if (idx >= 0) {
+                    do {
+                        v = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2);
+                    } while ((v >> 62) == 0);
+                }
+                const uint64_t full = __ballot((v >> 62) == 2);
+                const int stop = full ? __ffsll((unsigned long long)full) - 1 : 64;   // nearest inclusive prefix
+                uint64_t part = lane <= (uint32_t)stop ? (v & ((1ull << 62) - 1)) : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (full) break;
+                j -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&st[u], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            sh_base = excl;
+            a.unit_count[u] = total;
+        }
+    }
+    __syncthreads();
+
+    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    // ---- phase 2: emit
+    uint64_t run = sh_base;
+    const uint64_t cap = a.out_capacity;
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    if (out == nullptr || a.ablate == 3) return;
+    for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
+        uint32_t c[FJ_V];
+        uint2 first[FJ_V];
+        uint4 q[FJ_V];
+        bool ok[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
+            ok[k] = i < un.count;
+            c[k] = ok[k] ? scnt[i] : 0;
+            first[k] = ok[k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
+            q[k] = ok[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+        }
+        // saturated counts: recount from the index (also yields the exact number to emit)
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            if (c[k] == 255u) {
+                const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
+                const uint32_t t = t32_tag(h);
+                uint32_t n = 0, at = X.head(X.slot(h));
+                while (at != 0) {
+                    const uint32_t nd = X.node[at - 1u];
+                    if ((nd >> 16) == t) { const uint4 v = bd4[at - 1u]; n += (v.x == q[k].x && v.y == q[k].y); }
+                    at = nd & 0xffffu;
+                }
+                c[k] = n;
+            }
+        }
+        uint32_t off[FJ_V], wrun = 0;
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            uint32_t tot;
+            off[k] = wrun + wave_excl_scan_u32(c[k], &tot);
+            wrun += tot;
+        }
+        __syncthreads();                              // wsum reuse
+        if (lane == 0) wsum[w] = wrun;
+        __syncthreads();
+        uint64_t wbase = run;
+        uint32_t batch_total = 0;
+#pragma unroll
+        for (int i = 0; i < FJ_WAVES; ++i) {
+            const uint32_t v = wsum[i];
+            if ((uint32_t)i < w) wbase += v;
+            batch_total += v;
+        }
+        run += batch_total;
+        // single matches straight from the stash; duplicates in lockstep rounds over the table
+        uint64_t at[FJ_V];
+        uint32_t cur[FJ_V], tg[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            at[k] = wbase + off[k];
+            if (c[k] == 1 && at[k] < cap) out[at[k]] = make_pair(flip, q[k].z, q[k].w, first[k].x, first[k].y);
+            const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
+            tg[k] = t32_tag(h);
+            cur[k] = c[k] >= 2 ? X.head(X.slot(h)) : 0;
+        }
+        for (;;) {
+            uint32_t pos[FJ_V];
+            if (!fj_walk_round(X, cur, tg, pos)) break;
+            uint4 g[FJ_V];
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k)
+                g[k] = pos[k] != 0xffffffffu ? bd4[pos[k]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                if (pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y) {
+                    if (at[k] < cap) out[at[k]] = make_pair(flip, q[k].z, q[k].w, g[k].z, g[k].w);
+                    ++at[k];
+                }
+            }
+        }
+    }
+    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+}
+
+// total matches of the fused path = inclusive prefix of the last unit
+__global__ void k_fused_total(const uint64_t *status, const PlanSummary *summary, uint64_t *total_out)
+{
+    const uint64_t n = summary->units;
+    *total_out = n ? (status[n - 1] & ((1ull << 62) - 1)) : 0;
 }
 
 // Exclusive scan of n u64 counts (one workgroup, chunked); total -> *total_out.

@@ -18,8 +18,16 @@ def rhj():
     mod = importlib.import_module("sigmod-2018_amd")
     r = mod.RHJ(device=0)
     yield r
-    r.lib.rhj_set_force_hbm_table(0)
+    set_path(r, "fused")
     r.lib.rhj_set_empty_mode(0)
+
+
+PATHS = ["fused", "tiled32", "tiled64"]
+
+
+def set_path(rhj, path):
+    rhj.lib.rhj_set_fused(1 if path == "fused" else 0)
+    rhj.lib.rhj_set_force_hbm_table(1 if path == "tiled64" else 0)
 
 
 def dev_join(rhj, R, S):
@@ -29,16 +37,16 @@ def dev_join(rhj, R, S):
     return out
 
 
-@pytest.mark.parametrize("force_hbm", [0, 1])
-def test_synthetic_golden_device(rhj, golden, oracle, force_hbm):
-    rhj.lib.rhj_set_force_hbm_table(force_hbm)
+@pytest.mark.parametrize("path", PATHS)
+def test_synthetic_golden_device(rhj, golden, oracle, path):
+    set_path(rhj, path)
     for c in golden.synthetic["cases"]:
-        if force_hbm and c["R"]["n"] + c["S"]["n"] > 600000:
+        if path == "tiled64" and c["R"]["n"] + c["S"]["n"] > 600000:
             continue
         rhj.set_bits(c["bits"])
         R, S = golden.gen(c["R"]), golden.gen(c["S"])
-        assert_digest(oracle, dev_join(rhj, R, S), c, "%s hbm=%d" % (c["name"], force_hbm))
-    rhj.lib.rhj_set_force_hbm_table(0)
+        assert_digest(oracle, dev_join(rhj, R, S), c, "%s path=%s" % (c["name"], path))
+    set_path(rhj, "fused")
 
 
 def test_edge_cases_host_abi(rhj, golden):
@@ -69,8 +77,10 @@ def test_last_bucket_skew(rhj, golden, oracle):
     assert_digest(oracle, dev_join(rhj, make_rel(vals), make_rel(vals[np.array(k["perm"])])), k["t1"], "skew")
 
 
-def test_small_workload_joins(rhj, golden, oracle):
+@pytest.mark.parametrize("path", ["fused", "tiled32"])
+def test_small_workload_joins(rhj, golden, oracle, path):
     rhj.set_bits(4)
+    set_path(rhj, path)
     for j in golden.small["joins"]:
         R, S = golden.small_join(j["idx"])
         if j["idx"] % 4 == 0:
@@ -78,6 +88,7 @@ def test_small_workload_joins(rhj, golden, oracle):
         else:
             got = dev_join(rhj, R, S)
         assert_digest(oracle, got, j, "small join %d" % j["idx"])
+    set_path(rhj, "fused")
 
 
 def test_small_workload_filters(rhj, golden, oracle):
@@ -121,8 +132,11 @@ def test_random_joins_vs_oracle(rhj, oracle, bits, nR, nS, kind, dom):
     R = oracle.generate(nR, 0 if kind != 4 else 4, dom, 0.0, 5 + bits)
     S = oracle.generate(nS, kind, dom, 0.9, 6 + bits)
     want = oracle.join(R, S, bits)
-    got = dev_join(rhj, R, S)
-    assert len(got) == len(want) and (got == want).all()
+    for path in ("fused", "tiled32"):
+        set_path(rhj, path)
+        got = dev_join(rhj, R, S)
+        assert len(got) == len(want) and (got == want).all(), path
+    set_path(rhj, "fused")
 
 
 def test_capacity_overflow_reports_count(rhj, oracle):

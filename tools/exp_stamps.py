@@ -1,0 +1,35 @@
+import importlib, ctypes as C, torch, sys, os
+import numpy as np
+sys.path.insert(0, ".")
+import bench
+os.environ["RHJ_STAMPS"] = "1"
+mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
+nR, nS = [int(x) for x in sys.argv[1:3]]
+w = dict(nR=nR, nS=nS, bits=12, dist="uniform")
+rhj.set_bits(12)
+R, S = bench.make_relations(w, rhj.dev, 1234)
+cap = max(nR, nS)
+out = torch.empty((cap, 2), dtype=torch.int64, device=rhj.dev)
+m = C.c_uint64(0)
+for i in range(3):
+    rhj.lib.rhj_join_device(R.data_ptr(), nR, S.data_ptr(), nS, out.data_ptr(), cap, C.byref(m))
+st = rhj.stats()
+units = st["units"]
+buf = np.zeros((units, 8), dtype=np.uint64)
+rhj.lib.rhj_debug_stamps.argtypes = [C.c_void_p, C.c_uint64]
+assert rhj.lib.rhj_debug_stamps(buf.ctypes.data_as(C.c_void_p), units) == 0
+t = buf.astype(np.int64)
+t0 = t[:, 0].min()
+us = lambda a: a / 100.0
+print("fused %.3f ms, units %d" % (st["ms_probe"], units))
+print("span (first start -> last end): %.1f us" % us(t[:, 4].max() - t0))
+for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("phase1(w15 end)-(w0 end)", 2, 5), ("chain+barrier", 2, 3), ("phase2", 3, 4), ("unit total", 0, 4)):
+    d = us(t[:, b] - t[:, a])
+    print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+starts = np.sort(us(t[:, 0] - t0))
+print("start times of units 0,255,256,511,1024,4095: ", [round(float(starts[i]), 1) for i in (0, 255, 256, 511, 1024, units - 1)])
+
+for name, col, hi in (("p1 load", 6, True), ("p1 walk", 6, False), ("p1 gather", 7, True), ("p1 stash", 7, False)):
+    v = (buf[:, col] >> np.uint64(32)) if hi else (buf[:, col] & np.uint64(0xffffffff))
+    d = us(v.astype(np.int64))
+    print("%-28s mean %.1f  p50 %.1f  max %.1f us (wave 1, drained at every stamp)" % (name, d.mean(), np.median(d), d.max()))
