@@ -116,29 +116,46 @@ def check_properties(R, S, out, m, w):
 
 
 def cpu_baseline(w):
-    """The reference's own code (oracle/_ref, THREADS=1 build of rhjoin.c) — or, when that
-    binary is absent, this repo's restatement (oracle/rhj_oracle.c) — timed on the host cores
-    over a bounded sample of the same workload (same distribution and radix bits)."""
+    """The reference's own code (oracle/_ref: the THREADS=1 build of rhjoin.c/preprocess.c, the
+    authoritative mode, SURVEY.md finding 4) — or, when that binary is absent, this repo's
+    restatement (oracle/rhj_oracle.c) — timed on the host cores over a bounded sample of the same
+    workload (same distribution and radix bits).  The sample grows until one call takes a few
+    seconds, so the whole leg stays around 10-30 s of CPU work on any host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     o = pyoracle.Oracle()
-    scale = 10 if w["nS"] > w["nR"] else 1
-    nR = min(w["nR"], 8_000_000 if scale == 1 else 2_000_000)
-    nS = nR * scale
-    R = o.generate(nR, 3 if w["dist"] == "dense" else 0, 0, 0.0, 42)
-    S = o.generate(nS, {"uniform": 1, "zipf": 2, "dense": 4}[w["dist"]], nR, 0.9, 43)
-    if w["dist"] == "dense":
-        S["value"] += 1
-    if pyoracle.ref_available(w["bits"], 1):
-        ref = pyoracle.Reference(w["bits"], 1)
-        _, info = ref.join(R, S, with_info=True)
-        secs, kind = info["seconds"], "reference"
-    else:
-        t = time.time(); o.join(R, S, w["bits"]); secs = time.time() - t
-        kind = "port"
-    return {"value": nS / secs / 1e9, "unit": "10^9 probe tuples/s", "cores": 1, "kind": kind,
-            "sample": "%dx%d %s, %d radix bits, one RadixHashJoin call, %.2f s" % (nR, nS, w["dist"], w["bits"], secs),
-            "host_cpus": os.cpu_count()}
+    scale = w["nS"] // w["nR"]
+    use_ref = pyoracle.ref_available(w["bits"], 1)
+    ref = pyoracle.Reference(w["bits"], 1) if use_ref else None
+    nR, best = min(w["nR"], 4_000_000 // max(scale // 2, 1)), None
+    spent = 0.0
+    while True:
+        nS = nR * scale
+        R = o.generate(nR, 3 if w["dist"] == "dense" else 0, 0, 0.0, 42)
+        S = o.generate(nS, {"uniform": 1, "zipf": 2, "dense": 4}[w["dist"]], nR, 0.9, 43)
+        if w["dist"] == "dense":
+            S["value"] += 1
+        t = time.time()
+        if use_ref:
+            _, info = ref.join(R, S, with_info=True)
+            secs = info["seconds"]
+        else:
+            o.join(R, S, w["bits"])
+            secs = time.time() - t
+        spent += time.time() - t
+        best = (nR, nS, secs)
+        del R, S
+        if secs >= 3.0 or spent >= 12.0 or nR >= w["nR"] or nR * 4 * scale * 80 > 40e9:
+            break
+        nR = min(w["nR"], nR * 4)
+    nR, nS, secs = best
+    return {"value": nS / secs / 1e9, "unit": "10^9 probe tuples/s", "cores": 1,
+            "kind": "reference" if use_ref else "port",
+            "sample": "%dx%d %s, %d radix bits, one RadixHashJoin call (THREADS=1 path), %.2f s" % (
+                nR, nS, w["dist"], w["bits"], secs),
+            "host_cpus": os.cpu_count(),
+            "note": "the shipped THREADS=4 partitioner is O(buckets x N) and wrong on skew (SURVEY.md findings 3-4); "
+                    "the serial path is the reference's faster and correct mode"}
 
 
 def main():
@@ -218,6 +235,10 @@ def main():
         def gbs(b, ms):
             return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
+        fused = stage["ms_count"] == 0.0 and stage["ms_probe"] > 0
+        join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
+        probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
+                        else "k_probe<WRITE> (emit pass of the tiled path)")
         res = {
             "metric": "probe throughput (10^9 tuples/s) + achieved HBM GB/s",
             "value": world * nS * args.steps / elapsed / 1e9,
@@ -228,18 +249,27 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": w["name"], "id": args.workload, "nR": nR, "nS": nS, "radix_bits": w["bits"],
                        "matches": M, "parallelism": "independent join per GPU" if world > 1 else "1 GPU",
-                       "units": st["units"], "hbm_table_units": st["hbm_units"], "max_build_side": st["max_build"]},
-            "roofline": {"bound": "hbm", "kernel": "k_probe<WRITE> (probe + emit)",
+                       "path": "fused" if fused else "tiled", "units": st["units"], "max_build_side": st["max_build"]},
+            "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"]},
+                         "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"],
+                         "formula": "16*nS + 16*nR + 16*matches (SURVEY.md 8d)"},
             "kernels": {
                 "probe_tuples_per_s_e9": nS / (stage["ms_probe"] * 1e-3) / 1e9 if stage["ms_probe"] > 0 else 0.0,
-                "count": {"ms": stage["ms_count"], "GBps": gbs(count_bytes, stage["ms_count"])},
-                "scatter": {"ms": stage["ms_scatter"], "GBps": gbs(scatter_bytes, stage["ms_scatter"])},
-                "hist": {"ms": stage["ms_hist"], "GBps": gbs(hist_bytes, stage["ms_hist"])},
-                "scan": {"ms": stage["ms_scan"]}, "plan": {"ms": stage["ms_plan"]},
-                "build_hbm": {"ms": stage["ms_build"]}, "offsets": {"ms": stage["ms_offsets"]},
+                "join_phase_ms": join_ms,
+                "join_phase_GBps": gbs(probe_bytes, join_ms),
+                "partition": {"ms": stage["ms_hist"] + stage["ms_scan"] + stage["ms_scatter"],
+                              "GBps": gbs(hist_bytes + scatter_bytes, stage["ms_hist"] + stage["ms_scan"] + stage["ms_scatter"]),
+                              "algorithmic_bytes": hist_bytes + scatter_bytes,
+                              "formula": "16*n read (pass-1 histogram) + 16*n read + 16*n written (scatter), both relations"},
+                "hist_pass1": {"ms": stage["ms_hist"], "GBps": gbs(hist_bytes, stage["ms_hist"])},
+                "scan_pass1": {"ms": stage["ms_scan"]},
+                "scatter_all": {"ms": stage["ms_scatter"],
+                                "what": "scatter pass 1" + ("" if w["bits"] <= 8 else " + histogram, scan and scatter of pass 2")},
+                "plan": {"ms": stage["ms_plan"]},
+                "build_tables": {"ms": stage["ms_build"]}, "count": {"ms": stage["ms_count"]},
+                "offsets": {"ms": stage["ms_offsets"]},
                 "gpu_total_ms": stage["ms_total"],
             },
         }

@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rhj.h declares, and its
+host-only pieces (result lists, scheduler tokens, knobs) behave like results.c /
+scheduler.c.  No compute entry point is called here (they need a GPU)."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mod():
+    m = importlib.import_module("sigmod-2018_amd")
+    if not os.path.exists(m.LIB_PATH):
+        m.build()
+    return m
+
+
+@pytest.fixture(scope="module")
+def lib(mod):
+    return mod.load_library()
+
+
+def test_exports_every_declared_symbol(mod, lib):
+    hdr = open(os.path.join(ROOT, "include", "rhj.h")).read()
+    hdr = hdr.split("#ifdef RHJ_REFERENCE_NAMES")[0]
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)                 # comments out
+    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{()]*\)\s*;", hdr))
+    assert declared == set(mod.ABI_SYMBOLS), declared ^ set(mod.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_layouts_match_the_reference_structs(mod):
+    assert C.sizeof(mod.Relation) == 16 and C.sizeof(mod.Result) == 24 and C.sizeof(mod.FilterPred) == 16
+    assert C.sizeof(mod.RelationMap) == 32 and C.sizeof(mod.InterRes) == 24 and C.sizeof(mod.InterData) == 16
+    assert mod.TUPLE.itemsize == 16 and mod.PAIR.itemsize == 16
+
+
+def test_result_list_api_behaves_like_results_c(mod, lib):
+    head = C.POINTER(mod.Result)()
+    n = 8192 * 2 + 5                      # RESULT_MAX_BUFFER / 16 = 8192 pairs per node (structs.h:9)
+    pair = (C.c_uint64 * 2)()
+    for i in range(n):
+        pair[0], pair[1] = i, 2 * i
+        lib.InsertResult(C.byref(head), pair)
+    loads, p = [], head
+    while p:
+        loads.append(p.contents.current_load)
+        p = p.contents.next
+    assert loads == [8192, 8192, 5] and lib.GetResultNum(head) == n
+    for i in (0, 8191, 8192, n - 1):
+        t = C.cast(lib.FindResultTuples(head, i), C.POINTER(C.c_uint64))
+        assert (t[0], t[1]) == (i, 2 * i)
+    assert lib.FindResultTuples(head, -1) is None
+    lib.FreeResult(head)
+
+    ids = C.POINTER(mod.Result)()
+    m = 131072 + 3                        # RESULT_FINAL_BUFFER / 8 ids per node (structs.h:10)
+    v = C.c_uint64()
+    for i in range(m):
+        v.value = 3 * i
+        lib.InsertRowIdResult(C.byref(ids), C.byref(v))
+    assert lib.GetResultNum(ids) == m and ids.contents.current_load == 131072
+    assert lib.FindResultRowId(ids, 131073) == 3 * 131073
+    lib.FreeResult(ids)
+    lib.FreeResult(None)
+
+
+def test_scheduler_tokens_and_knobs(lib):
+    sched = C.c_void_p()
+    lib.SchedulerInit.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.SchedulerDestroy.argtypes = [C.c_void_p]
+    assert lib.SchedulerInit(C.byref(sched), 4) == 0 and sched.value
+    assert lib.SchedulerDestroy(sched) == 0
+    keep = lib.rhj_get_radix_bits()
+    assert lib.rhj_set_radix_bits(0) == -1 and lib.rhj_set_radix_bits(13) == -1
+    assert lib.rhj_set_radix_bits(12) == 0 and lib.rhj_get_radix_bits() == 12
+    lib.rhj_set_radix_bits(keep)
+    assert b"gfx950" in lib.rhj_version()
