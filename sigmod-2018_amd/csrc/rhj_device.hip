@@ -131,7 +131,9 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
     const uint32_t bins = 1u << bits;
     uint32_t max_tiles = r0.tiles;
     if (nrel > 1 && r1.tiles > max_tiles) max_tiles = r1.tiles;
-    const uint32_t chunks = max_tiles >= 256 ? 32 : 1;
+    uint32_t chunks = (max_tiles + 15) / 16;                  // >= 16 tiles per chunk, at most 512 chunks
+    if (chunks > 512) chunks = 512;
+    if (chunks < 1) chunks = 1;
     if (ensure(g.chunk, (size_t)2 * chunks * bins * 8)) return -1;
     const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
     const size_t hist_lds = ((size_t)bins + (full_bits ? ((size_t)1 << full_bits) : 0)) * 4;
@@ -141,7 +143,8 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
     hipLaunchKernelGGL(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (uint64_t *)g.chunk.p);
-    hipLaunchKernelGGL(k_scan_bins, dim3(nrel), dim3(1024), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist, psum);
+    hipLaunchKernelGGL(k_scan_bins, dim3(bins, nrel), dim3(WAVE), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist);
+    hipLaunchKernelGGL(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint64_t *)hist, psum);
     hipLaunchKernelGGL(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));

@@ -193,9 +193,13 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
     }
 }
 
-// Scan step 1: per (bin, chunk of tiles) column sums.
+// Scan of the per-tile digit counts into per-tile start offsets, in four small kernels:
+//   k_scan_chunks  column sums per (digit, chunk of tiles)         -> chunk_sum[rel][digit][chunk]
+//   k_scan_bins    one wave per digit: exclusive scan over chunks  -> chunk_sum (in place), hist[rel][digit]
+//   k_scan_psum    exclusive scan over digits                      -> psum[rel][digit]
+//   k_scan_apply   counts -> psum[digit] + chunk prefix + tiles before this one (in place)
 __global__ __launch_bounds__(256) void k_scan_chunks(RelArgs r0, RelArgs r1, int bits, uint32_t chunks,
-                                                     uint64_t *chunk_sum /*[2][chunks][bins]*/)
+                                                     uint64_t *chunk_sum /*[2][bins][chunks]*/)
 {
     const RelArgs &r = blockIdx.z ? r1 : r0;
     const uint32_t bins = 1u << bits;
@@ -205,31 +209,40 @@ __global__ __launch_bounds__(256) void k_scan_chunks(RelArgs r0, RelArgs r1, int
     const uint32_t t0 = blockIdx.y * per, t1 = min(t0 + per, r.tiles);
     uint64_t s = 0;
     for (uint32_t t = t0; t < t1; ++t) s += r.cnt[(size_t)t * bins + b];
-    chunk_sum[((size_t)blockIdx.z * chunks + blockIdx.y) * bins + b] = s;
+    chunk_sum[((size_t)blockIdx.z * bins + b) * chunks + blockIdx.y] = s;
 }
 
-// Scan step 2 (one workgroup per relation): digit totals -> hist, exclusive scan over
-// digits -> psum, chunk sums -> exclusive chunk prefixes.
-__global__ __launch_bounds__(1024) void k_scan_bins(int bits, uint32_t chunks, uint64_t *chunk_sum,
-                                                    uint64_t *hist /*[2][bins]*/, uint64_t *psum /*[2][bins]*/)
+__global__ __launch_bounds__(WAVE) void k_scan_bins(int bits, uint32_t chunks, uint64_t *chunk_sum, uint64_t *hist)
+{
+    const uint32_t bins = 1u << bits;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    uint64_t *cs = chunk_sum + ((size_t)blockIdx.y * bins + b) * chunks;
+    uint64_t carry = 0;
+    for (uint32_t c0 = 0; c0 < chunks; c0 += WAVE) {
+        const uint32_t c = c0 + lane;
+        const uint64_t v = c < chunks ? cs[c] : 0;
+        uint64_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x += y;
+        }
+        if (c < chunks) cs[c] = carry + x - v;
+        carry += __shfl(x, 63, 64);
+    }
+    if (lane == 0) hist[(size_t)blockIdx.y * bins + b] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_psum(int bits, const uint64_t *hist, uint64_t *psum)
 {
     __shared__ uint64_t sm[1024 / 64 + 1];
     const uint32_t bins = 1u << bits;
-    uint64_t *cs = chunk_sum + (size_t)blockIdx.x * chunks * bins;
-    uint64_t *h = hist + (size_t)blockIdx.x * bins, *p = psum + (size_t)blockIdx.x * bins;
-    const uint32_t per = (bins + 1023) / 1024;       // consecutive bins per thread
+    const uint64_t *h = hist + (size_t)blockIdx.x * bins;
+    uint64_t *p = psum + (size_t)blockIdx.x * bins;
+    const uint32_t per = (bins + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per;
     uint64_t mine = 0;
-    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) {
-        uint64_t run = 0;
-        for (uint32_t c = 0; c < chunks; ++c) {
-            const uint64_t t = cs[(size_t)c * bins + b];
-            cs[(size_t)c * bins + b] = run;
-            run += t;
-        }
-        h[b] = run;
-        mine += run;
-    }
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) mine += h[b];
     uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
     for (uint32_t b = b0; b < min(b0 + per, bins); ++b) {
         p[b] = base;
@@ -237,7 +250,6 @@ __global__ __launch_bounds__(1024) void k_scan_bins(int bits, uint32_t chunks, u
     }
 }
 
-// Scan step 3: counts -> start offsets  psum[bin] + (tiles before this one).
 __global__ __launch_bounds__(256) void k_scan_apply(RelArgs r0, RelArgs r1, int bits, uint32_t chunks,
                                                     const uint64_t *chunk_sum, const uint64_t *psum)
 {
@@ -247,8 +259,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(RelArgs r0, RelArgs r1, int 
     if (b >= bins) return;
     const uint32_t per = (r.tiles + chunks - 1) / chunks;
     const uint32_t t0 = blockIdx.y * per, t1 = min(t0 + per, r.tiles);
-    uint64_t run = psum[(size_t)blockIdx.z * bins + b] +
-                   chunk_sum[((size_t)blockIdx.z * chunks + blockIdx.y) * bins + b];
+    uint64_t run = psum[(size_t)blockIdx.z * bins + b] + chunk_sum[((size_t)blockIdx.z * bins + b) * chunks + blockIdx.y];
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t c = r.cnt[(size_t)t * bins + b];
         r.cnt[(size_t)t * bins + b] = (uint32_t)run;

@@ -1,0 +1,39 @@
+"""GPU: the reference's own engine (its caller side compiled unchanged in the build
+container and linked against librhj.so: oracle/_ref/radixhash_rhj, see oracle/Makefile and
+INTEGRATION.md) answers the SIGMOD'18 `small` workload with our RadixHashJoin()/Filter()
+doing the hot path, and must reproduce the reference's golden file small.result line by
+line.  The relation files are rebuilt from the committed fixture."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENGINE = os.path.join(ROOT, "oracle", "_ref", "radixhash_rhj")
+
+
+@pytest.mark.skipif(not os.path.exists(ENGINE), reason="oracle/_ref/radixhash_rhj not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("empty_mode", ["head", "null"])
+def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode):
+    rels = golden.small_relations
+    names = []
+    for i in range(14):
+        cols = rels["r%d" % i].astype("<u8")
+        path = tmp_path / ("r%d" % i)
+        with open(path, "wb") as f:
+            np.array([cols.shape[1], cols.shape[0]], dtype="<u8").tofile(f)     # tuples, columns
+            cols.tofile(f)                                                       # column-major
+        names.append("r%d" % i)
+    stdin = "\n".join(names) + "\nDone\n" + "\n".join(golden.small["work_lines"]) + "\n"
+    env = dict(os.environ, RHJ_EMPTY=empty_mode, RHJ_RADIX_BITS="4")
+    res = subprocess.run([ENGINE], input=stdin.encode(), cwd=str(tmp_path), env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    got = res.stdout.decode().splitlines()
+    want = golden.small["result_lines"]
+    assert len(got) == len(want) == 50
+    bad = [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w]
+    assert not bad, bad[:5]
