@@ -145,6 +145,9 @@ void rhj_set_stream(void *hip_stream);
  *                    (64-bit entries), the path of buckets beyond 65534 build tuples. */
 void rhj_set_fused(int on);
 void rhj_set_force_hbm_table(int on);
+/* Fused path only: 1 (default) copies a bucket's build tuples into LDS when they fit beside
+ * the index (<= ~7 K tuples: no global gather at all), 0 always gathers them from HBM. */
+void rhj_set_resident(int on);
 
 /* ---- device-resident entry points (what RadixHashJoin()/Filter() call
  *      after staging; bench.py and the parity tests call them directly) ----- */

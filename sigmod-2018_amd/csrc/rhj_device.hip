@@ -47,6 +47,7 @@ struct Ctx {
     int         force_hbm = 0;
     int         ablate = 0;
     int         no_fused = 0;
+    int         no_resident = 0;
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
@@ -71,6 +72,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
         if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);
         if ((e = getenv("RHJ_NO_FUSED"))) g.no_fused = atoi(e);
+        if ((e = getenv("RHJ_NO_RESIDENT"))) g.no_resident = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
     }
 } env_defaults;
@@ -99,7 +101,9 @@ int ctx_init()
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
     // dynamic LDS above 64 KiB has to be requested per kernel
     HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     g.ready = true;
@@ -300,7 +304,10 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         }
         uint64_t M = 0;
         const uint64_t mb = plan.max_build < 64 ? 64 : plan.max_build;
-        const size_t fused_lds = (((size_t)mb + 3) & ~(size_t)3) * 4 + (mb + 1) / 2 * 4 + 16;
+        const size_t mbp = ((size_t)mb + 3) & ~(size_t)3;
+        size_t fused_lds = mbp * 4 + (mb + 1) / 2 * 4 + 16;
+        const bool resident = !g.no_resident && fused_lds + mbp * 16 <= LDS_BUDGET - FJ_LDS_EXTRA;
+        if (resident) fused_lds += mbp * 16;                  // build tuples live in LDS too: no gathers, no stash
         if (use_ctx_out) {
             const uint64_t guess = (nR > nS ? nR : nS) + 1024;
             if (g.out.cap < guess * sizeof(rhj_result_tuple) && ensure(g.out, guess * sizeof(rhj_result_tuple))) return -1;
@@ -315,8 +322,10 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
             HIP_TRY(hipMemsetAsync(g.status.p, 0, (plan.units + 1) * 8 + 64, g.stream));
-            if (plan.units)
-                hipLaunchKernelGGL(k_join_fused, dim3((unsigned)plan.units), dim3(FJ_BLOCK), fused_lds, g.stream, fa);
+            if (plan.units) {
+                if (resident) hipLaunchKernelGGL(k_join_fused<true>, dim3((unsigned)plan.units), dim3(FJ_BLOCK), fused_lds, g.stream, fa);
+                else          hipLaunchKernelGGL(k_join_fused<false>, dim3((unsigned)plan.units), dim3(FJ_BLOCK), fused_lds, g.stream, fa);
+            }
             hipLaunchKernelGGL(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
                                (const PlanSummary *)g.summary.p, &((PlanSummary *)g.summary.p)->matches);
             HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
@@ -457,6 +466,7 @@ void rhj_set_empty_mode(int null_on_empty) { g.null_on_empty = null_on_empty; }
 void rhj_set_node_pairs(uint64_t pairs) { g.node_pairs = pairs; }
 void rhj_set_force_hbm_table(int on) { g.force_hbm = on; }
 void rhj_set_fused(int on) { g.no_fused = !on; }
+void rhj_set_resident(int on) { g.no_resident = !on; }
 /* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */
 int rhj_debug_stamps(uint64_t *host, uint64_t units)
 {

@@ -877,9 +877,12 @@ __global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
 // One workgroup per unit = (bucket, up to FJ_SPAN probe tuples), taken in canonical order
 // through a ticket so that a unit's predecessors are always running or done.
 //   build    ordered 32-bit table of the bucket's build side in LDS
-//   phase 1  stream the unit's probe tuples; table walk in LDS; ONE global gather per
+//   phase 1  stream the unit's probe tuples; chain walk in LDS; ONE global gather per
 //            candidate (key to verify + row id); per probe tuple stash the match count
 //            (u8) and the first match's build row id (u64), coalesced
+//            (RES variant, build side <= ~7 K tuples: the build tuples themselves are
+//            copied into LDS during the build, so there is no global gather and no stash;
+//            phase 2 simply probes the LDS index again)
 //   chain    publish the unit's match total, decoupled look-back over the predecessors
 //            (one 8-byte {flag,value} word per unit, agent-scope relaxed atomics)
 //   phase 2  stream probe row ids + stash and write the pairs at their final canonical
@@ -974,6 +977,42 @@ __device__ __forceinline__ bool fj_walk_round(const FjIndex &X, uint32_t (&cur)[
     return __ballot(found) != 0;
 }
 
+// Count the matches of one batch (FJ_V probe tuples per lane): lockstep rounds of
+// {walk every live chain to its next tag hit (LDS), fetch those candidates' build tuples
+// together, verify the 64-bit keys}.  RES: the build tuples are resident in LDS (no global
+// access at all); otherwise each candidate is one 16-byte gather from the bucket's build side.
+template <bool RES>
+__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd4, const uint4 *ltup,
+                                               const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
+                                               uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V])
+{
+    uint32_t cur[FJ_V], tg[FJ_V];
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
+        tg[k] = t32_tag(h);
+        cur[k] = okk[k] ? X.head(X.slot(h)) : 0;
+        c[k] = 0; flo[k] = 0; fhi[k] = 0;
+    }
+    for (;;) {
+        uint32_t pos[FJ_V];
+        if (!fj_walk_round(X, cur, tg, pos)) break;
+        uint4 g[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            g[k] = make_uint4(0, 0, 0, 0);
+            if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : bd4[pos[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
+            if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
+            c[k] += eq;
+        }
+    }
+}
+
+template <bool RES>
 __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
@@ -995,10 +1034,13 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
     const rhj_tuple *pr = (flip ? a.partS : a.partR) + ppos;
     const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
     const uint32_t bc = (uint32_t)(flip ? cR : cS);
+    // LDS: [resident build tuples 16 B x bc] [node 4 B x bc] [head links 2 B x hs]
+    const uint32_t bcp = (bc + 3u) & ~3u;
+    uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
     FjIndex X;
-    X.node = tbl;
+    X.node = tbl + (RES ? 4u * bcp : 0u);
     X.hs = bc < 64u ? 64u : bc;
-    X.headw = tbl + ((bc + 3u) & ~3u);
+    X.headw = X.node + bcp;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
     uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
@@ -1009,84 +1051,48 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
     for (uint32_t sidx = threadIdx.x; sidx < (X.hs + 1u) / 2u; sidx += FJ_BLOCK) X.headw[sidx] = 0;
     __syncthreads();
     for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
-        uint64_t key[FJ_V];
+        uint4 t[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = i0 + k * FJ_BLOCK + threadIdx.x;
-            key[k] = i < bc ? bd[i].value : 0;
+            t[k] = make_uint4(0, 0, 0, 0);
+            if (i < bc) { if (RES) t[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; t[k].x = kv.x; t[k].y = kv.y; } }
         }
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = i0 + k * FJ_BLOCK + threadIdx.x;
-            if (i < bc) fj_insert(X, key[k], i);
+            if (i < bc) {
+                if (RES) ltup[i] = t[k];
+                fj_insert(X, ((uint64_t)t[k].y << 32) | t[k].x, i);
+            }
         }
     }
     __syncthreads();
     if (a.ablate == 1) return;                        // timing experiment: build only
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
-    // ---- phase 1: count + stash.  Candidates are taken in lockstep rounds: every round
-    // walks each tuple's table run (LDS) to its next tag hit and issues the gathers of all
-    // of them together, so a batch costs max-multiplicity round trips, not one per candidate.
+    // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
     uint32_t mine = 0;
-    uint64_t acc_load = 0, acc_walk = 0, acc_gather = 0, acc_stash = 0, tA = 0;
-#define FJ_STAMP(accum)                                                                 \
-    if (f.dbg) {                                                                        \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                     \
-        const uint64_t now_ = __builtin_amdgcn_s_memrealtime();                         \
-        accum += now_ - tA; tA = now_;                                                  \
-    }
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
         uint4 q[FJ_V];
-        uint32_t cur[FJ_V], tg[FJ_V];
-        uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
-        if (f.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tA = __builtin_amdgcn_s_memrealtime(); }
         bool okk[FJ_V];
+        uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
             okk[k] = i < un.count;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
-#pragma unroll
-        for (int k = 0; k < FJ_V; ++k) {
-            const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
-            tg[k] = t32_tag(h);
-            cur[k] = okk[k] ? X.head(X.slot(h)) : 0;
-            c[k] = 0; flo[k] = 0; fhi[k] = 0;
-        }
-        FJ_STAMP(acc_load)
-        for (;;) {
-            uint32_t pos[FJ_V];
-            const bool any = fj_walk_round(X, cur, tg, pos);
-            FJ_STAMP(acc_walk)
-            if (!any) break;
-            uint4 g[FJ_V];
-#pragma unroll
-            for (int k = 0; k < FJ_V; ++k)
-                g[k] = (pos[k] != 0xffffffffu && a.ablate != 2) ? bd4[pos[k]] : q[k];
-            FJ_STAMP(acc_gather)
-#pragma unroll
-            for (int k = 0; k < FJ_V; ++k) {
-                const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
-                if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
-                c[k] += eq;
-            }
-        }
+        fj_count_batch<RES>(X, bd4, ltup, q, okk, c, flo, fhi);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
-            if (i < un.count && a.ablate != 4) {
+            if (!RES && i < un.count) {
                 scnt[i] = (uint8_t)min(c[k], 255u);
                 reinterpret_cast<uint2 *>(srow)[i] = make_uint2(flo[k], fhi[k]);
             }
             mine += c[k];
         }
-        FJ_STAMP(acc_stash)
-    }
-    if (f.dbg && threadIdx.x == 64) {       // wave 1's view
-        f.dbg[(size_t)u * 8 + 6] = (acc_load << 32) | acc_walk;
-        f.dbg[(size_t)u * 8 + 7] = (acc_gather << 32) | acc_stash;
     }
 
     // ---- unit total -> chained scan
@@ -1141,31 +1147,37 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     if (out == nullptr || a.ablate == 3) return;
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
-        uint32_t c[FJ_V];
-        uint2 first[FJ_V];
+        uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
         uint4 q[FJ_V];
-        bool ok[FJ_V];
+        bool okk[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
-            ok[k] = i < un.count;
-            c[k] = ok[k] ? scnt[i] : 0;
-            first[k] = ok[k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
-            q[k] = ok[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+            okk[k] = i < un.count;
+            q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+            if (!RES) {
+                c[k] = okk[k] ? scnt[i] : 0;
+                const uint2 fr = okk[k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
+                flo[k] = fr.x; fhi[k] = fr.y;
+            }
         }
-        // saturated counts: recount from the index (also yields the exact number to emit)
+        if (RES) {
+            fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi);      // LDS only: cheaper than a stash round trip
+        } else {
+            // saturated counts: recount from the index (also yields the exact number to emit)
 #pragma unroll
-        for (int k = 0; k < FJ_V; ++k) {
-            if (c[k] == 255u) {
-                const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
-                const uint32_t t = t32_tag(h);
-                uint32_t n = 0, at = X.head(X.slot(h));
-                while (at != 0) {
-                    const uint32_t nd = X.node[at - 1u];
-                    if ((nd >> 16) == t) { const uint4 v = bd4[at - 1u]; n += (v.x == q[k].x && v.y == q[k].y); }
-                    at = nd & 0xffffu;
+            for (int k = 0; k < FJ_V; ++k) {
+                if (c[k] == 255u) {
+                    const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
+                    const uint32_t t = t32_tag(h);
+                    uint32_t n = 0, at = X.head(X.slot(h));
+                    while (at != 0) {
+                        const uint32_t nd = X.node[at - 1u];
+                        if ((nd >> 16) == t) { const uint4 v = bd4[at - 1u]; n += (v.x == q[k].x && v.y == q[k].y); }
+                        at = nd & 0xffffu;
+                    }
+                    c[k] = n;
                 }
-                c[k] = n;
             }
         }
         uint32_t off[FJ_V], wrun = 0;
@@ -1187,13 +1199,13 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
             batch_total += v;
         }
         run += batch_total;
-        // single matches straight from the stash; duplicates in lockstep rounds over the table
+        // single matches directly; duplicates in lockstep rounds over the chains
         uint64_t at[FJ_V];
         uint32_t cur[FJ_V], tg[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             at[k] = wbase + off[k];
-            if (c[k] == 1 && at[k] < cap) out[at[k]] = make_pair(flip, q[k].z, q[k].w, first[k].x, first[k].y);
+            if (c[k] == 1 && at[k] < cap) out[at[k]] = make_pair(flip, q[k].z, q[k].w, flo[k], fhi[k]);
             const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
             tg[k] = t32_tag(h);
             cur[k] = c[k] >= 2 ? X.head(X.slot(h)) : 0;
@@ -1203,8 +1215,10 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
             if (!fj_walk_round(X, cur, tg, pos)) break;
             uint4 g[FJ_V];
 #pragma unroll
-            for (int k = 0; k < FJ_V; ++k)
-                g[k] = pos[k] != 0xffffffffu ? bd4[pos[k]] : make_uint4(0, 0, 0, 0);
+            for (int k = 0; k < FJ_V; ++k) {
+                g[k] = make_uint4(0, 0, 0, 0);
+                if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : bd4[pos[k]];
+            }
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
                 if (pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y) {

@@ -22,11 +22,12 @@ def rhj():
     r.lib.rhj_set_empty_mode(0)
 
 
-PATHS = ["fused", "tiled32", "tiled64"]
+PATHS = ["fused", "fused_gather", "tiled32", "tiled64"]
 
 
 def set_path(rhj, path):
-    rhj.lib.rhj_set_fused(1 if path == "fused" else 0)
+    rhj.lib.rhj_set_fused(1 if path.startswith("fused") else 0)
+    rhj.lib.rhj_set_resident(0 if path == "fused_gather" else 1)
     rhj.lib.rhj_set_force_hbm_table(1 if path == "tiled64" else 0)
 
 
@@ -77,7 +78,7 @@ def test_last_bucket_skew(rhj, golden, oracle):
     assert_digest(oracle, dev_join(rhj, make_rel(vals), make_rel(vals[np.array(k["perm"])])), k["t1"], "skew")
 
 
-@pytest.mark.parametrize("path", ["fused", "tiled32"])
+@pytest.mark.parametrize("path", ["fused", "fused_gather", "tiled32"])
 def test_small_workload_joins(rhj, golden, oracle, path):
     rhj.set_bits(4)
     set_path(rhj, path)
@@ -126,13 +127,14 @@ def test_partition_matches_oracle(rhj, oracle, bits):
     (3, 1000, 1, 4, 10), (7, 77777, 99999, 1, 50000), (9, 200000, 1000, 4, 1 << 20),
     (12, 2000000, 3000000, 1, 2000000), (12, 100000, 3000000, 2, 100000), (4, 50000, 60000, 4, 11),
     (4, 800000, 900000, 1, 800000), (2, 300000, 500000, 1, 300000),
+    (4, 300000, 350000, 1, 300000), (4, 350000, 300000, 1, 350000), (6, 400000, 400000, 4, 90000),
 ])
 def test_random_joins_vs_oracle(rhj, oracle, bits, nR, nS, kind, dom):
     rhj.set_bits(bits)
     R = oracle.generate(nR, 0 if kind != 4 else 4, dom, 0.0, 5 + bits)
     S = oracle.generate(nS, kind, dom, 0.9, 6 + bits)
     want = oracle.join(R, S, bits)
-    for path in ("fused", "tiled32"):
+    for path in ("fused", "fused_gather", "tiled32"):
         set_path(rhj, path)
         got = dev_join(rhj, R, S)
         assert len(got) == len(want) and (got == want).all(), path
