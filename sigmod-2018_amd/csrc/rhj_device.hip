@@ -32,7 +32,7 @@ struct Buf {
     size_t cap = 0;
 };
 
-constexpr int MAX_BITS = 12;
+constexpr int MAX_BITS = 14;
 constexpr uint32_t LDS_BUDGET = 160 * 1024;       // bytes per workgroup on gfx950
 
 enum Stage { ST_HIST, ST_SCAN, ST_SCATTER, ST_PLAN, ST_BUILD, ST_COUNT, ST_OFFSETS, ST_PROBE, ST_END, ST_N };
@@ -67,7 +67,7 @@ struct EnvDefaults {
     {
         const char *e;
         if ((e = getenv("RHJ_DEVICE"))) g.device = atoi(e);
-        if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 12) g.bits = b; }
+        if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 14) g.bits = b; }
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
         if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);
@@ -101,6 +101,7 @@ int ctx_init()
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
     // dynamic LDS above 64 KiB has to be requested per kernel
     HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_hist_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
