@@ -52,7 +52,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
@@ -194,6 +194,18 @@ int run_partition(PartState &ps, int bits, int nrel)
     hipLaunchKernelGGL(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
                        ps.psum);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// exclusive scan of up to max_n u64 counts (device-side count in *n_ptr when given)
+int launch_offsets(const uint64_t *cnt, uint64_t *base, const uint64_t *n_ptr, uint64_t n_fixed, uint64_t max_n,
+                   uint64_t *total_out)
+{
+    const uint32_t nblocks = (uint32_t)((max_n + 1023) / 1024 ? (max_n + 1023) / 1024 : 1);
+    if (ensure(g.bsum, (size_t)nblocks * 8)) return -1;
+    hipLaunchKernelGGL(k_offsets_local, dim3(nblocks), dim3(1024), 0, g.stream, cnt, base, n_ptr, n_fixed, (uint64_t *)g.bsum.p);
+    hipLaunchKernelGGL(k_offsets_blocks, dim3(1), dim3(1024), 0, g.stream, (uint64_t *)g.bsum.p, nblocks, total_out);
+    hipLaunchKernelGGL(k_offsets_add, dim3(nblocks), dim3(1024), 0, g.stream, base, n_ptr, n_fixed, (const uint64_t *)g.bsum.p);
     return 0;
 }
 
@@ -370,9 +382,10 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     if (plan.units)
         hipLaunchKernelGGL((k_probe<false>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
     HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
-                       (const uint64_t *)&((PlanSummary *)g.summary.p)->units, (uint64_t)0,
-                       &((PlanSummary *)g.summary.p)->matches);
+    if (launch_offsets((const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
+                       (const uint64_t *)&((PlanSummary *)g.summary.p)->units, 0, plan.units,
+                       &((PlanSummary *)g.summary.p)->matches))
+        return -1;
     HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #2: match count -> output size
     const uint64_t M = hs->matches;
@@ -423,7 +436,7 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
     if (oc < 0) return -3;
     if (n == 0) return 0;
     const uint64_t tiles = (n + FILTER_TILE - 1) / FILTER_TILE;
-    if (ensure(g.fmask, ((n + 63) / 64 + FILTER_ROUNDS * 4) * 8) || ensure(g.ftile, tiles * 8) ||
+    if (ensure(g.fmask, ((n + 63) / 64 + FILTER_ROUNDS * 8 + 8) * 8) || ensure(g.ftile, tiles * 8) ||
         ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary)))
         return -1;
     if (use_ctx_out) {
@@ -435,8 +448,7 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
     HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
     hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
                        (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p,
-                       (const uint64_t *)nullptr, tiles, total);
+    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
     hipLaunchKernelGGL(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
                        (const uint64_t *)g.fbase.p, d_out);
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
@@ -546,7 +558,7 @@ void rhj_release(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);
