@@ -52,7 +52,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
@@ -131,7 +131,7 @@ size_t scatter_lds_bytes(int bits)
 
 // one stable pass over both relations: per-tile histogram, scan, LDS-staged scatter
 int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int full_bits, uint64_t *hist, uint64_t *psum,
-                   bool first)
+                   bool first, int next_shift = 0, int next_bits = 0)
 {
     const uint32_t bins = 1u << bits;
     uint32_t max_tiles = r0.tiles;
@@ -154,7 +154,7 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
                        chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
     hipLaunchKernelGGL(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1,
-                       shift, bits);
+                       shift, bits, next_shift, next_bits);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -170,7 +170,7 @@ int run_partition(PartState &ps, int bits, int nrel)
     if (ensure(g.histpsum, (size_t)4 * bins * 8) || ensure(g.passhp, (size_t)4 * 256 * 8)) return -1;
     ps.hist = (uint64_t *)g.histpsum.p;
     ps.psum = ps.hist + 2 * bins;
-    RelArgs none = RelArgs{nullptr, nullptr, nullptr, 0, 0, 0};
+    RelArgs none = RelArgs{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
     for (int i = 0; i < nrel; ++i) ps.r[i].tiles = tiles_for(ps.r[i].n);
     if (ensure(g.cntR, (size_t)ps.r[0].tiles * 256 * 4)) return -1;
     ps.r[0].cnt = (uint32_t *)g.cntR.p;
@@ -187,9 +187,17 @@ int run_partition(PartState &ps, int bits, int nrel)
     HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
     RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
     RelArgs b0 = a0, b1 = a1;
+    // pass 1 also writes every output tuple's pass-2 digit (1 B), so the pass-2 histogram reads n
+    // bytes instead of the 16n-byte tuples
+    if (ensure(g.digR, ps.r[0].n + 64)) return -1;
     a0.out = ps.tmp[0]; b0.in = ps.tmp[0];
-    if (nrel > 1) { a1.out = ps.tmp[1]; b1.in = ps.tmp[1]; }
-    if (partition_pass(a0, a1, nrel, 0, lo, bits, ph, pp, true)) return -1;
+    a0.dig_out = (uint8_t *)g.digR.p; b0.dig_in = (const uint8_t *)g.digR.p;
+    if (nrel > 1) {
+        if (ensure(g.digS, ps.r[1].n + 64)) return -1;
+        a1.out = ps.tmp[1]; b1.in = ps.tmp[1];
+        a1.dig_out = (uint8_t *)g.digS.p; b1.dig_in = (const uint8_t *)g.digS.p;
+    }
+    if (partition_pass(a0, a1, nrel, 0, lo, bits, ph, pp, true, lo, hi)) return -1;
     if (partition_pass(b0, b1, nrel, lo, hi, 0, ph, pp, false)) return -1;
     hipLaunchKernelGGL(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
                        ps.psum);
@@ -240,8 +248,8 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
 
     PartState ps;
     if (ensure(g.partR, nR * sizeof(rhj_tuple)) || ensure(g.partS, nS * sizeof(rhj_tuple))) return -1;
-    ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0};
-    ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0};
+    ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0, nullptr, nullptr};
+    ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0, nullptr, nullptr};
     ps.tmp[0] = ps.tmp[1] = nullptr;
     if (bits > PT_MAX_BITS) {
         if (ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple))) return -1;
@@ -517,7 +525,7 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
     const uint32_t bins = 1u << bits;
     if (n >= (1ull << 32)) return -2;
     PartState ps;
-    ps.r[0] = RelArgs{d_in, d_out, nullptr, n, 0, 0};
+    ps.r[0] = RelArgs{d_in, d_out, nullptr, n, 0, 0, nullptr, nullptr};
     ps.tmp[0] = ps.tmp[1] = nullptr;
     if (bits > PT_MAX_BITS) {
         if (ensure(g.tmpR, (n ? n : 1) * sizeof(rhj_tuple))) return -1;
@@ -558,7 +566,7 @@ void rhj_release(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);

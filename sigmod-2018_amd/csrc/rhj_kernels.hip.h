@@ -49,6 +49,8 @@ struct RelArgs {                 // one relation through one partition pass
     uint64_t         n;
     uint32_t         tiles;
     uint32_t         pad;
+    const uint8_t   *dig_in;     // pass 2: this pass' digit per input tuple, written by pass 1 (else null)
+    uint8_t         *dig_out;    // pass 1 of a two-pass partition: next pass' digit per OUTPUT tuple (else null)
 };
 
 struct Unit {
@@ -172,11 +174,22 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
         __syncthreads();
         const uint64_t beg = (uint64_t)tile * PT_TILE;
         const uint64_t end = min(beg + (uint64_t)PT_TILE, r.n);
+        if (r.dig_in) {                               // digits were precomputed by the previous pass: 1 B per tuple
+            const uint32_t *d4 = reinterpret_cast<const uint32_t *>(r.dig_in + beg);
+            const uint32_t cnt = (uint32_t)(end - beg);
+            for (uint32_t j = threadIdx.x; j < (cnt + 3) / 4; j += 256) {
+                const uint32_t v = d4[j];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (4 * j + t < cnt) atomicAdd(&tile_h[(v >> (8 * t)) & 0xffu], 1u);
+            }
+        } else {
 #pragma unroll 4
-        for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
-            const uint64_t k = r.in[i].value;
-            atomicAdd(&tile_h[(uint32_t)(k >> shift) & mask], 1u);
-            if (full_bits) atomicAdd(&full_h[(uint32_t)k & fmask], 1u);
+            for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+                const uint64_t k = r.in[i].value;
+                atomicAdd(&tile_h[(uint32_t)(k >> shift) & mask], 1u);
+                if (full_bits) atomicAdd(&full_h[(uint32_t)k & fmask], 1u);
+            }
         }
         __syncthreads();
         uint32_t *row = r.cnt + (size_t)tile * bins;
@@ -292,7 +305,8 @@ __global__ __launch_bounds__(1024) void k_full_psum(int bits, const uint32_t *fu
 //   wave) + (same digit in lower lanes of this round)
 // computed with one match-any (bits ballots) per round and per-wave LDS counters — no
 // atomics, so the placement does not depend on any hardware ordering.
-__global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits)
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift,
+                                                          int next_bits)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
@@ -378,7 +392,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
             const uint4 v = stage[p];
             const uint64_t key = ((uint64_t)v.y << 32) | v.x;
             const uint32_t d = (uint32_t)(key >> shift) & mask;
-            out[(uint32_t)(delta[d] + p)] = v;
+            const uint32_t dst = delta[d] + p;
+            out[dst] = v;
+            if (r.dig_out) r.dig_out[dst] = (uint8_t)((uint32_t)(key >> next_shift) & ((1u << next_bits) - 1u));
         }
     }
 }
