@@ -283,19 +283,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     PlanSummary *hs = (PlanSummary *)g.pin;
-    HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #1: launch geometry
-    PlanSummary plan = *hs;
-    bool fused = want_fused && plan.build_units == 0;         // every bucket's table fits LDS
-    if (want_fused && !fused) {                               // some bucket needs an HBM table: tiled path for all
-        pa.span_lds = PR_UNIT;
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
-        HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        plan = *hs;
-    }
-    st.units = plan.units; st.hbm_units = plan.build_units; st.max_build = plan.max_build;
-    st.table_slots = plan.hbm_slots + plan.tab32_slots;
+    PlanSummary plan;
 
     JoinArgs ja;
     ja.partR = (const rhj_tuple *)g.partR.p; ja.partS = (const rhj_tuple *)g.partS.p;
@@ -308,27 +296,28 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     ja.out = nullptr; ja.out_capacity = 0;
     ja.ablate = (uint32_t)g.ablate; ja.pad = 0;
 
-    if (fused) {
-        // ---- fused LDS path: build + probe + emit in one kernel, chained output offsets
+    if (want_fused) {
+        // ---- fused LDS path: build + probe + emit in one kernel, chained output offsets.  Launched
+        // without waiting for the plan: the grid is the host-side upper bound on the unit count, the
+        // LDS allocation the maximum, and the kernel itself returns when the plan found a bucket that
+        // does not fit LDS (then the tiled path below takes over).  One host sync per join.
+        const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / FJ_SPAN + 2;
         if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
-            ensure(g.status, (plan.units + 1) * 8 + 64))
+            ensure(g.status, (unit_bound + 1) * 8 + 64))
             return -1;
         FusedArgs fa;
         fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
         fa.status = (uint64_t *)g.status.p + 8;               // words 0..7 hold the ticket
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
+        fa.allow_resident = !g.no_resident; fa.pad = 0;
         fa.dbg = nullptr;
         if (getenv("RHJ_STAMPS")) {                           // diagnostic runs only
-            if (ensure(g.dbg, (plan.units + 1) * 64)) return -1;
+            if (ensure(g.dbg, (unit_bound + 1) * 64)) return -1;
             fa.dbg = (uint64_t *)g.dbg.p;
         }
         uint64_t M = 0;
-        const uint64_t mb = plan.max_build < 64 ? 64 : plan.max_build;
-        const size_t mbp = ((size_t)mb + 3) & ~(size_t)3;
-        size_t fused_lds = mbp * 4 + (mb + 1) / 2 * 4 + 16;
-        const bool resident = !g.no_resident && fused_lds + mbp * 16 <= LDS_BUDGET - FJ_LDS_EXTRA;
-        if (resident) fused_lds += mbp * 16;                  // build tuples live in LDS too: no gathers, no stash
+        const uint32_t fused_lds = LDS_BUDGET - FJ_LDS_EXTRA;
         if (use_ctx_out) {
             const uint64_t guess = (nR > nS ? nR : nS) + 1024;
             if (g.out.cap < guess * sizeof(rhj_result_tuple) && ensure(g.out, guess * sizeof(rhj_result_tuple))) return -1;
@@ -339,37 +328,54 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
         HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
         HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+        bool fused_done = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
-            HIP_TRY(hipMemsetAsync(g.status.p, 0, (plan.units + 1) * 8 + 64, g.stream));
-            if (plan.units) {
-                if (resident) hipLaunchKernelGGL(k_join_fused<true>, dim3((unsigned)plan.units), dim3(FJ_BLOCK), fused_lds, g.stream, fa);
-                else          hipLaunchKernelGGL(k_join_fused<false>, dim3((unsigned)plan.units), dim3(FJ_BLOCK), fused_lds, g.stream, fa);
-            }
+            HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
+            // the resident variant only when an average bucket could fit beside the index (~7.4 K tuples)
+            if (nmin / bins <= 7000 && !g.no_resident)
+                hipLaunchKernelGGL(k_join_fused<true>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            else
+                hipLaunchKernelGGL(k_join_fused<false>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             hipLaunchKernelGGL(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
                                (const PlanSummary *)g.summary.p, &((PlanSummary *)g.summary.p)->matches);
             HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
             HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
-            M = hs->matches;
+            plan = *hs;
+            if (!plan.fused_ok) break;
+            fused_done = true;
+            M = plan.matches;
             if (!use_ctx_out || M <= out_capacity) break;
             if (ensure(g.out, M * sizeof(rhj_result_tuple))) return -1;    // rare: fan-out above the guess
             out = (rhj_result_tuple *)g.out.p;
             out_capacity = M;
         }
-        *matches = M;
-        st.matches = M;
-        if (ctx_out) *ctx_out = out;
-        st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
-        st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
-        st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
-        st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
-        st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
-        st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
-        return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
+        if (fused_done) {
+            st.units = plan.units; st.hbm_units = 0; st.max_build = plan.max_build;
+            *matches = M;
+            st.matches = M;
+            if (ctx_out) *ctx_out = out;
+            st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
+            st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
+            st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
+            st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
+            st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
+            st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+            return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
+        }
+        // some bucket needs an HBM table: plan again with tile-granular units
+        pa.span_lds = PR_UNIT;
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+        if (use_ctx_out) { out = nullptr; out_capacity = 0; }
     }
+    HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));                  // tiled path: launch geometry
+    plan = *hs;
+    st.units = plan.units; st.hbm_units = plan.build_units; st.max_build = plan.max_build;
+    st.table_slots = plan.hbm_slots + plan.tab32_slots;
 
     if (ensure(g.tab32, max_tab32 * 4)) return -1;
     ja.tab32 = (uint32_t *)g.tab32.p;

@@ -73,7 +73,9 @@ struct PlanSummary {
     uint64_t tab32_slots;        // total slots of all 32-bit tables
     uint64_t max_lds_slots;      // largest 32-bit table
     uint64_t max_build;          // largest build side
-    uint64_t matches;            // filled by k_offsets
+    uint64_t matches;            // filled by k_offsets / k_fused_total
+    uint64_t fused_ok;           // every active bucket's build side <= lds_cap (fused path usable)
+    uint64_t pad;
 };
 
 struct JoinArgs {
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
         PlanSummary s;
         s.units = tot_u; s.build_units = tot_b; s.hbm_slots = tot_s64; s.lds_buckets = tot_l;
         s.tab32_slots = tot_s32; s.max_lds_slots = red[1]; s.max_build = red[0]; s.matches = 0;
+        s.fused_ok = tot_b == 0; s.pad = 0;
         *a.summary = s;
     }
 }
@@ -919,6 +922,8 @@ struct FusedArgs {
     uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
     uint32_t *ticket;
     uint64_t  nR;
+    uint32_t  allow_resident;
+    uint32_t  pad;
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
 };
 
@@ -1042,8 +1047,10 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd
     }
 }
 
-template <bool RES>
-__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
+// MAYRES = false compiles the gather path only (the host picks it when the average bucket
+// cannot fit LDS anyway); MAYRES = true decides per unit.
+template <bool MAYRES>
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
     __shared__ uint32_t sh_u;
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
     if (threadIdx.x == 0) sh_u = atomicAdd(f.ticket, 1u);
     __syncthreads();
     const uint32_t u = sh_u;
-    if (u >= a.summary->units) return;
+    if (u >= a.summary->units || !a.summary->fused_ok) return;        // grid is an upper bound; tiled path takes over
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
     const uint64_t cR = a.histR[b], cS = a.histS[b];
@@ -1066,10 +1073,13 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
     const uint32_t bc = (uint32_t)(flip ? cR : cS);
     // LDS: [resident build tuples 16 B x bc] [node 4 B x bc] [head links 2 B x hs]
     const uint32_t bcp = (bc + 3u) & ~3u;
+    const uint32_t hs0 = bc < 64u ? 64u : bc;
+    // build tuples go to LDS too when they fit beside the index (wave-uniform per unit)
+    const bool RES = MAYRES && f.allow_resident && (size_t)bcp * 20 + (size_t)(hs0 + 1) / 2 * 4 + 16 <= lds_bytes;
     uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
     FjIndex X;
     X.node = tbl + (RES ? 4u * bcp : 0u);
-    X.hs = bc < 64u ? 64u : bc;
+    X.hs = hs0;
     X.headw = X.node + bcp;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
     uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
@@ -1113,7 +1123,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f)
             okk[k] = i < un.count;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
-        fj_count_batch<RES>(X, bd4, ltup, q, okk, c, flo, fhi);
+        if (RES) fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi);
+        else     fj_count_batch<false>(X, bd4, ltup, q, okk, c, flo, fhi);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
