@@ -81,7 +81,8 @@ def build():
     subprocess.check_call(["make", "-s", "-C", HERE, "all"])
 
 
-def load_library():
+def load_library(path=None):
+    LIB_PATH = path or globals()["LIB_PATH"]
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("librhj.so is not built (run `make -C sigmod-2018_amd` or __graft_entry__.build()); "
                            "this package has no CPU fallback")
@@ -129,12 +130,12 @@ def _np_ptr(a):
 class RHJ:
     """Device and host entry points of librhj.so."""
 
-    def __init__(self, device=None, use_torch_stream=True):
+    def __init__(self, device=None, use_torch_stream=True, lib_path=None):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the radix hash join has no CPU path")
-        self.lib = load_library()
+        self.lib = load_library(lib_path)
         if device is not None:
             self.lib.rhj_set_device(int(device))
             torch.cuda.set_device(int(device))
