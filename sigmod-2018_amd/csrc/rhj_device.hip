@@ -55,6 +55,8 @@ struct Ctx {
         ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
+    void *pin_out[2] = {nullptr, nullptr};   // D2H staging of result pairs
+    hipEvent_t ev_pin[2] = {};
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
     rhj_stats stats = {};
 };
@@ -602,12 +604,43 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
     *matches = M;
     if (M == 0) return 0;
     if (node_pairs == 0) node_pairs = M;
+    // D2H through two pinned staging blocks (a pageable destination measured 5.7 GB/s): the copy of
+    // block i+1 runs while block i is memcpy'd into the caller-visible malloc'd nodes
+    const uint64_t blk = (uint64_t)4 << 20;                               // pairs per staging block (64 MiB)
+    if (!g.pin_out[0]) {
+        HIP_TRY(hipHostMalloc(&g.pin_out[0], blk * sizeof(rhj_result_tuple), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&g.pin_out[1], blk * sizeof(rhj_result_tuple), hipHostMallocDefault));
+        HIP_TRY(hipEventCreate(&g.ev_pin[0]));
+        HIP_TRY(hipEventCreate(&g.ev_pin[1]));
+    }
     HIP_TRY(hipEventRecord(g.ev_x[2], g.stream));
-    for (uint64_t at = 0; at < M; at += node_pairs) {
-        const uint64_t cnt = M - at < node_pairs ? M - at : node_pairs;
-        void *dst = alloc_chunk(ctx, cnt);
-        if (!dst) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)cnt); return -1; }
-        HIP_TRY(hipMemcpyAsync(dst, d_out + at, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream));
+    const uint64_t nblk = (M + blk - 1) / blk;
+    char *node_dst = nullptr;                                             // fill cursor inside the current node
+    uint64_t node_left = 0;
+    for (uint64_t b = 0; b <= nblk; ++b) {
+        if (b < nblk) {
+            const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
+            HIP_TRY(hipMemcpyAsync(g.pin_out[b & 1], d_out + b * blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipEventRecord(g.ev_pin[b & 1], g.stream));
+        }
+        if (b > 0) {
+            const uint64_t pb = b - 1;
+            uint64_t cnt = M - pb * blk < blk ? M - pb * blk : blk;
+            HIP_TRY(hipEventSynchronize(g.ev_pin[pb & 1]));
+            const char *src = (const char *)g.pin_out[pb & 1];
+            while (cnt) {
+                if (node_left == 0) {
+                    const uint64_t done = pb * blk + (uint64_t)(src - (const char *)g.pin_out[pb & 1]) / sizeof(rhj_result_tuple);
+                    node_left = M - done < node_pairs ? M - done : node_pairs;
+                    node_dst = (char *)alloc_chunk(ctx, node_left);
+                    if (!node_dst) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)node_left); return -1; }
+                }
+                const uint64_t take = cnt < node_left ? cnt : node_left;
+                memcpy(node_dst, src, take * sizeof(rhj_result_tuple));
+                node_dst += take * sizeof(rhj_result_tuple); src += take * sizeof(rhj_result_tuple);
+                node_left -= take; cnt -= take;
+            }
+        }
     }
     HIP_TRY(hipEventRecord(g.ev_x[3], g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
