@@ -1019,7 +1019,7 @@ __device__ __forceinline__ uint4 fj_gather(const uint4 *p)
 template <bool RES>
 __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd4, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
-                                               uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V])
+                                               uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V])
 {
     uint32_t cur[FJ_V], tg[FJ_V];
 #pragma unroll
@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd
         const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
         tg[k] = t32_tag(h);
         cur[k] = okk[k] ? X.head(X.slot(h)) : 0;
-        c[k] = 0; flo[k] = 0; fhi[k] = 0;
+        c[k] = 0; flo[k] = 0; fhi[k] = 0; fp[k] = false;
     }
     for (;;) {
         uint32_t pos[FJ_V];
@@ -1043,6 +1043,7 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd
             const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
             if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
             c[k] += eq;
+            fp[k] = fp[k] || (pos[k] != 0xffffffffu && !eq);      // a tag hit with a different key
         }
     }
 }
@@ -1117,19 +1118,22 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         uint4 q[FJ_V];
         bool okk[FJ_V];
         uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
+        bool fp[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
             okk[k] = i < un.count;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
-        if (RES) fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi);
-        else     fj_count_batch<false>(X, bd4, ltup, q, okk, c, flo, fhi);
+        if (RES) fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi, fp);
+        else     fj_count_batch<false>(X, bd4, ltup, q, okk, c, flo, fhi, fp);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
             if (!RES && i < un.count) {
-                scnt[i] = (uint8_t)min(c[k], 255u);
+                // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
+                // this tuple was a different key, so phase 2 must verify its candidates again
+                scnt[i] = (uint8_t)(min(c[k], 127u) | (fp[k] ? 0x80u : 0u));
                 reinterpret_cast<uint2 *>(srow)[i] = make_uint2(flo[k], fhi[k]);
             }
             mine += c[k];
@@ -1190,25 +1194,28 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
         uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
         uint4 q[FJ_V];
-        bool okk[FJ_V];
+        bool okk[FJ_V], fpt[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
             okk[k] = i < un.count;
+            fpt[k] = false;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
             if (!RES) {
-                c[k] = okk[k] ? scnt[i] : 0;
+                const uint32_t sb = okk[k] ? scnt[i] : 0;
+                c[k] = sb & 0x7fu;
+                fpt[k] = (sb & 0x80u) != 0;
                 const uint2 fr = okk[k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
                 flo[k] = fr.x; fhi[k] = fr.y;
             }
         }
         if (RES) {
-            fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi);      // LDS only: cheaper than a stash round trip
+            fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi, fpt);  // LDS only: cheaper than a stash round trip
         } else {
             // saturated counts: recount from the index (also yields the exact number to emit)
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
-                if (c[k] == 255u) {
+                if (c[k] == 127u) {
                     const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
                     const uint32_t t = t32_tag(h);
                     uint32_t n = 0, at = X.head(X.slot(h));
@@ -1240,20 +1247,31 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             batch_total += v;
         }
         run += batch_total;
-        // single matches directly; duplicates in lockstep rounds over the chains
+        // The first match comes from the stash (phase 1 kept its row id).  Further matches of a tuple
+        // are fetched in lockstep rounds over its chain; when no tag hit of the tuple was a foreign key
+        // (the rule: stash bit 7 clear) its first candidate IS that first match and is skipped unfetched.
         uint64_t at[FJ_V];
         uint32_t cur[FJ_V], tg[FJ_V];
+        bool skip[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             at[k] = wbase + off[k];
-            if (c[k] == 1 && at[k] < cap) out[at[k]] = make_pair(flip, q[k].z, q[k].w, flo[k], fhi[k]);
+            const bool direct = c[k] >= 1 && !fpt[k];             // stash holds its first emitted pair
+            if (direct) { if (at[k] < cap) out[at[k]] = make_pair(flip, q[k].z, q[k].w, flo[k], fhi[k]); ++at[k]; }
             const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
             tg[k] = t32_tag(h);
-            cur[k] = c[k] >= 2 ? X.head(X.slot(h)) : 0;
+            const bool walk = direct ? c[k] >= 2 : c[k] >= 1;
+            cur[k] = walk ? X.head(X.slot(h)) : 0;
+            skip[k] = direct;
         }
-        for (;;) {
+        for (bool first_round = true;; first_round = false) {
             uint32_t pos[FJ_V];
             if (!fj_walk_round(X, cur, tg, pos)) break;
+            if (first_round) {
+#pragma unroll
+                for (int k = 0; k < FJ_V; ++k)
+                    if (skip[k]) pos[k] = 0xffffffffu;            // already emitted from the stash
+            }
             uint4 g[FJ_V];
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
