@@ -1002,22 +1002,30 @@ __device__ __forceinline__ bool fj_walk_round(const FjIndex &X, uint32_t (&cur)[
 // {walk every live chain to its next tag hit (LDS), fetch those candidates' build tuples
 // together, verify the 64-bit keys}.  RES: the build tuples are resident in LDS (no global
 // access at all); otherwise each candidate is one 16-byte gather from the bucket's build side.
-// A gather of one build tuple, issued as a non-temporal load: each gathered line is used
-// once per candidate, and nt measured 10 % off the fused kernel on MI355X (4.64 -> 4.06 ms
-// on 100Mx100M@12; -DRHJ_GATHER_PLAIN restores the default policy for A/B runs).
-__device__ __forceinline__ uint4 fj_gather(const uint4 *p)
-{
-#ifndef RHJ_GATHER_PLAIN
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
+// Gathers of build tuples go through a buffer descriptor of the bucket's build side and carry
+// sc1 (L1 bypass): a gathered line is used once per candidate, so allocating it in the 32 KiB
+// vector L1 only evicts the streamed probe data.  A/B on MI355X (tools/ab.py, fused kernel on
+// 100Mx100M@12): plain 4.64 ms, nt 4.06 ms, sc1 3.8 ms.
+struct FjGather {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ void init(const rhj_tuple *bd, uint32_t bc)
+    {
+        const uint64_t addr = (uint64_t)bd;                       // wave-uniform by construction: make it provable
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        const uint32_t bytes = __builtin_amdgcn_readfirstlane(bc * 16u);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+    }
+    __device__ __forceinline__ uint4 load(uint32_t pos) const
+    {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, 16 /* sc1 */);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+};
 
 template <bool RES>
-__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd4, const uint4 *ltup,
+__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather &G, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
                                                uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V])
 {
@@ -1036,7 +1044,7 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const uint4 *bd
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             g[k] = make_uint4(0, 0, 0, 0);
-            if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : fj_gather(bd4 + pos[k]);
+            if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : G.load(pos[k]);
         }
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
@@ -1086,6 +1094,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
     const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
+    FjGather G;
+    G.init(bd, bc);
 
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
@@ -1125,8 +1135,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             okk[k] = i < un.count;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
-        if (RES) fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi, fp);
-        else     fj_count_batch<false>(X, bd4, ltup, q, okk, c, flo, fhi, fp);
+        if (RES) fj_count_batch<true>(X, G, ltup, q, okk, c, flo, fhi, fp);
+        else     fj_count_batch<false>(X, G, ltup, q, okk, c, flo, fhi, fp);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
@@ -1210,7 +1220,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         if (RES) {
-            fj_count_batch<true>(X, bd4, ltup, q, okk, c, flo, fhi, fpt);  // LDS only: cheaper than a stash round trip
+            fj_count_batch<true>(X, G, ltup, q, okk, c, flo, fhi, fpt);    // LDS only: cheaper than a stash round trip
         } else {
             // saturated counts: recount from the index (also yields the exact number to emit)
 #pragma unroll
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                     uint32_t n = 0, at = X.head(X.slot(h));
                     while (at != 0) {
                         const uint32_t nd = X.node[at - 1u];
-                        if ((nd >> 16) == t) { const uint4 v = bd4[at - 1u]; n += (v.x == q[k].x && v.y == q[k].y); }
+                        if ((nd >> 16) == t) { const uint4 v = G.load(at - 1u); n += (v.x == q[k].x && v.y == q[k].y); }
                         at = nd & 0xffffu;
                     }
                     c[k] = n;
@@ -1276,7 +1286,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
                 g[k] = make_uint4(0, 0, 0, 0);
-                if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : bd4[pos[k]];
+                if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : G.load(pos[k]);
             }
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
