@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
         } else {
 #pragma unroll 4
             for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
-                const uint64_t k = r.in[i].value;
-                atomicAdd(&tile_h[(uint32_t)(k >> shift) & mask], 1u);
-                if (full_bits) atomicAdd(&full_h[(uint32_t)k & fmask], 1u);
+                const uint32_t k = (uint32_t)r.in[i].value;       // shift + bits and full_bits <= 16
+                atomicAdd(&tile_h[(k >> shift) & mask], 1u);
+                if (full_bits) atomicAdd(&full_h[k & fmask], 1u);
             }
         }
         __syncthreads();
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
     uint32_t *mycnt = wcnt + w * bins;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
-        const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;
+        const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch)
         const uint32_t d = (uint32_t)(key >> shift) & mask;
         dig[k] = d;
         uint64_t peers = __ballot(ok[k]);
@@ -392,11 +392,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
         const uint32_t p = k * PT_BLOCK + threadIdx.x;
         if (p < count) {
             const uint4 v = stage[p];
-            const uint64_t key = ((uint64_t)v.y << 32) | v.x;
-            const uint32_t d = (uint32_t)(key >> shift) & mask;
+            const uint32_t d = (v.x >> shift) & mask;
             const uint32_t dst = delta[d] + p;
             out[dst] = v;
-            if (r.dig_out) r.dig_out[dst] = (uint8_t)((uint32_t)(key >> next_shift) & ((1u << next_bits) - 1u));
+            if (r.dig_out) r.dig_out[dst] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
         }
     }
 }
