@@ -176,3 +176,44 @@ def check_join_properties(R, S, pairs, bits):
     probe_ids = np.where(probe_is_R, pairs["row_idR"], pairs["row_idS"]).astype(np.int64)
     same = np.diff(b) == 0
     assert (np.diff(probe_ids)[same] >= 0).all()
+
+
+def test_fuzz_shapes_bits_paths(rhj, oracle):
+    """Randomised sweep over sizes (ragged, tiny, one side empty), key distributions, radix widths and
+    paths in ONE process: also exercises the grow-only workspace across calls of varying size."""
+    rng = np.random.RandomState(20181004)
+    for it in range(60):
+        bits = int(rng.choice([1, 3, 4, 6, 8, 9, 12, 14]))
+        nR = int(rng.choice([0, 1, 2, 63, 64, 65, 1000, 4097, 30000, 200000]))
+        nS = int(rng.choice([0, 1, 5, 64, 129, 2500, 8191, 50000, 300000]))
+        kind = int(rng.choice([1, 2, 3, 4]))
+        dom = int(rng.choice([1, 7, 1000, 100000, 1 << 40]))
+        R = oracle.generate(nR, 4 if kind == 4 else 0 if kind != 3 else 3, dom, 0.0, 1000 + it)
+        S = oracle.generate(nS, kind, min(dom, max(nR, 1)) if kind != 4 else dom, 0.8, 2000 + it)
+        if rng.rand() < 0.3 and nR:
+            R["row_id"] = R["row_id"] * np.uint64(0x9E3779B97F4A7C15) + np.uint64(it)
+        path = PATHS[it % len(PATHS)]
+        set_path(rhj, path)
+        rhj.set_bits(bits)
+        want = oracle.join(R, S, bits)
+        got = dev_join(rhj, R, S) if (nR and nS) else rhj.RadixHashJoin(R, S)
+        assert len(got) == len(want) and (got == want).all(), (it, bits, nR, nS, kind, dom, path)
+    set_path(rhj, "fused")
+    rhj.lib.rhj_release()          # drops the workspace; the next call must rebuild it
+    R = oracle.generate(5000, 0, 0, 0.0, 1); S = oracle.generate(7000, 1, 5000, 0.0, 2)
+    rhj.set_bits(4)
+    assert (dev_join(rhj, R, S) == oracle.join(R, S, 4)).all()
+
+
+def test_full_size_properties_c3(rhj):
+    """BASELINE config 3 (100M x 100M uniform FK, 12 radix bits) at full size through the
+    size-independent properties (the oracle would need minutes): one pair per S tuple, equal keys,
+    S row ids a permutation, buckets ascending."""
+    import bench
+    w = bench.WORKLOADS["c3"]
+    rhj.set_bits(w["bits"])
+    R, S = bench.make_relations(w, rhj.dev, 99)
+    t, m = rhj.join_device(R, S, capacity=w["nS"])
+    bench.check_properties(R, S, t, m, w)
+    del R, S, t
+    rhj.torch.cuda.empty_cache()
