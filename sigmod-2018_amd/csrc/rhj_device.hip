@@ -264,7 +264,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     const bool want_fused = !g.no_fused && !g.force_hbm;
     const uint32_t lds_max_slots = LDS_BUDGET / 4 / 4 * 4;                 // tiled path: k_build_lds owns the whole LDS
     uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
-    if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 64) / 6;        // fused: 4 B node + 2 B head link per build tuple
+    if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 64) * 2 / 9;    // fused: 4 B node + >= 0.5 B of head links per build tuple
     if (lds_cap > 65534) lds_cap = 65534;                                  // 16-bit position + 1
     if (g.force_hbm) lds_cap = 0;
     const uint64_t nmin = nR < nS ? nR : nS;
@@ -281,7 +281,15 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk;
-    pa.span_lds = want_fused ? FJ_SPAN : PR_UNIT;
+    // probe tuples per fused unit: whole buckets when there are plenty of them, smaller spans (each unit
+    // rebuilds its bucket's index) when a low radix would otherwise leave most CUs idle
+    uint32_t fused_span = FJ_SPAN;
+    {
+        uint64_t want = ((nR > nS ? nR : nS) / 512 + FJ_BATCH - 1) / FJ_BATCH * FJ_BATCH;
+        if (want < FJ_BATCH) want = FJ_BATCH;
+        if (want < fused_span) fused_span = (uint32_t)want;
+    }
+    pa.span_lds = want_fused ? fused_span : PR_UNIT;
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     PlanSummary *hs = (PlanSummary *)g.pin;
@@ -303,7 +311,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         // without waiting for the plan: the grid is the host-side upper bound on the unit count, the
         // LDS allocation the maximum, and the kernel itself returns when the plan found a bucket that
         // does not fit LDS (then the tiled path below takes over).  One host sync per join.
-        const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / FJ_SPAN + 2;
+        const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;
         if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
             ensure(g.status, (unit_bound + 1) * 8 + 64))
             return -1;

@@ -1081,7 +1081,13 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     const uint32_t bc = (uint32_t)(flip ? cR : cS);
     // LDS: [resident build tuples 16 B x bc] [node 4 B x bc] [head links 2 B x hs]
     const uint32_t bcp = (bc + 3u) & ~3u;
-    const uint32_t hs0 = bc < 64u ? 64u : bc;
+    // head slots: one per build tuple when that fits behind the nodes, fewer (longer chains) for the
+    // largest build sides, never below a quarter (host-side cap: 4.5 B per build tuple)
+    uint32_t hs0 = bc < 64u ? 64u : bc;
+    {
+        const uint32_t room = (lds_bytes - 16u - 4u * bcp) / 2u;      // 16-bit links that still fit
+        if (hs0 > room) hs0 = room & ~1u;
+    }
     // build tuples go to LDS too when they fit beside the index (wave-uniform per unit)
     const bool RES = MAYRES && f.allow_resident && (size_t)bcp * 20 + (size_t)(hs0 + 1) / 2 * 4 + 16 <= lds_bytes;
     uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
