@@ -133,7 +133,10 @@ void rhj_set_empty_mode(int null_on_empty);
 void rhj_set_node_pairs(uint64_t pairs_per_node);
 /* Device ordinal (default 0 or env RHJ_DEVICE); must precede the first call. */
 int  rhj_set_device(int ordinal);
-/* Launch all work on this hipStream_t (passed as void*); NULL = own stream. */
+/* Launch all work on this hipStream_t (passed as void*).  NULL is HIP's default stream (work the
+ * caller queued there, e.g. through PyTorch's default stream, is then ordered before the join);
+ * without this call the library uses a non-blocking stream of its own and the caller must have
+ * synchronised its producers. */
 void rhj_set_stream(void *hip_stream);
 /* Path selection (results are identical on every path; tests run all three):
  *   fused (default)  one workgroup per bucket keeps its tag table in LDS, builds, probes and

@@ -42,6 +42,7 @@ struct Ctx {
     int         device = 0;
     hipStream_t stream = nullptr;
     bool        own_stream = false;
+    bool        stream_set = false;  // rhj_set_stream() was called (possibly with the null stream)
     int         bits = 4;
     int         null_on_empty = 0;
     int         force_hbm = 0;
@@ -97,7 +98,7 @@ int ctx_init()
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) { fprintf(stderr, "rhj: no HIP device visible; this library has no CPU path\n"); return -1; }
     HIP_TRY(hipSetDevice(g.device));
-    if (!g.stream) { HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true; }
+    if (!g.stream_set) { HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true; }
     for (auto &ev : g.ev) HIP_TRY(hipEventCreate(&ev));
     for (auto &ev : g.ev_x) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
@@ -518,9 +519,12 @@ int rhj_set_device(int ordinal)
 }
 void rhj_set_stream(void *s)
 {
-    if (g.own_stream && g.stream) { hipStreamDestroy(g.stream); g.own_stream = false; }
+    // s is a hipStream_t; NULL is HIP's default (null) stream, which is what PyTorch's default
+    // stream is: work the caller queued there is ordered before ours.  Until this is called the
+    // library launches on a non-blocking stream of its own.
+    if (g.own_stream && g.stream) { (void)hipStreamDestroy(g.stream); g.own_stream = false; }
     g.stream = (hipStream_t)s;
-    if (!s && g.ready) { hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking); g.own_stream = true; }
+    g.stream_set = true;
 }
 const rhj_stats *rhj_last_stats(void) { return &g.stats; }
 const char *rhj_version(void) { return "rhj-mi355x 0.1 (gfx950)"; }
