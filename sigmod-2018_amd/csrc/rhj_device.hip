@@ -27,6 +27,24 @@ using namespace rhj;
 
 namespace {
 
+// RHJ_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (the last name printed before
+// a "Memory access fault" is the kernel that faulted).  Diagnostic runs only.
+static int g_debug_sync = -1;
+static void debug_after_launch(const char *what, hipStream_t s)
+{
+    if (g_debug_sync < 0) g_debug_sync = getenv("RHJ_DEBUG_SYNC") ? 1 : 0;
+    if (!g_debug_sync) return;
+    fprintf(stderr, "rhj: launched %s\n", what);
+    fflush(stderr);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) fprintf(stderr, "rhj: %s -> %s\n", what, hipGetErrorString(e));
+}
+#define RHJ_LAUNCH(kernel, grid, block, lds, stream, ...)                       \
+    do {                                                                         \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
+        debug_after_launch(#kernel, stream);                                     \
+    } while (0)
+
 struct Buf {
     void  *p = nullptr;
     size_t cap = 0;
@@ -146,17 +164,17 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
     const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
     const size_t hist_lds = ((size_t)bins + (full_bits ? ((size_t)1 << full_bits) : 0)) * 4;
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    hipLaunchKernelGGL(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), hist_lds, g.stream, r0, r1, shift, bits,
+    RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), hist_lds, g.stream, r0, r1, shift, bits,
                        full_bits, (uint32_t *)g.fullhist.p);
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
-    hipLaunchKernelGGL(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
+    RHJ_LAUNCH(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (uint64_t *)g.chunk.p);
-    hipLaunchKernelGGL(k_scan_bins, dim3(bins, nrel), dim3(WAVE), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist);
-    hipLaunchKernelGGL(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint64_t *)hist, psum);
-    hipLaunchKernelGGL(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
+    RHJ_LAUNCH(k_scan_bins, dim3(bins, nrel), dim3(WAVE), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist);
+    RHJ_LAUNCH(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint64_t *)hist, psum);
+    RHJ_LAUNCH(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
-    hipLaunchKernelGGL(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1,
+    RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1,
                        shift, bits, next_shift, next_bits);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -202,7 +220,7 @@ int run_partition(PartState &ps, int bits, int nrel)
     }
     if (partition_pass(a0, a1, nrel, 0, lo, bits, ph, pp, true, lo, hi)) return -1;
     if (partition_pass(b0, b1, nrel, lo, hi, 0, ph, pp, false)) return -1;
-    hipLaunchKernelGGL(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
+    RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
                        ps.psum);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -214,9 +232,9 @@ int launch_offsets(const uint64_t *cnt, uint64_t *base, const uint64_t *n_ptr, u
 {
     const uint32_t nblocks = (uint32_t)((max_n + 1023) / 1024 ? (max_n + 1023) / 1024 : 1);
     if (ensure(g.bsum, (size_t)nblocks * 8)) return -1;
-    hipLaunchKernelGGL(k_offsets_local, dim3(nblocks), dim3(1024), 0, g.stream, cnt, base, n_ptr, n_fixed, (uint64_t *)g.bsum.p);
-    hipLaunchKernelGGL(k_offsets_blocks, dim3(1), dim3(1024), 0, g.stream, (uint64_t *)g.bsum.p, nblocks, total_out);
-    hipLaunchKernelGGL(k_offsets_add, dim3(nblocks), dim3(1024), 0, g.stream, base, n_ptr, n_fixed, (const uint64_t *)g.bsum.p);
+    RHJ_LAUNCH(k_offsets_local, dim3(nblocks), dim3(1024), 0, g.stream, cnt, base, n_ptr, n_fixed, (uint64_t *)g.bsum.p);
+    RHJ_LAUNCH(k_offsets_blocks, dim3(1), dim3(1024), 0, g.stream, (uint64_t *)g.bsum.p, nblocks, total_out);
+    RHJ_LAUNCH(k_offsets_add, dim3(nblocks), dim3(1024), 0, g.stream, base, n_ptr, n_fixed, (const uint64_t *)g.bsum.p);
     return 0;
 }
 
@@ -285,14 +303,14 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     // probe tuples per fused unit: whole buckets when there are plenty of them, smaller spans (each unit
     // rebuilds its bucket's index) when a low radix would otherwise leave most CUs idle
     uint32_t fused_span = FJ_SPAN;
-    {
+    if (bins < 256) {                                         // fewer buckets than CUs
         uint64_t want = ((nR > nS ? nR : nS) / 512 + FJ_BATCH - 1) / FJ_BATCH * FJ_BATCH;
         if (want < FJ_BATCH) want = FJ_BATCH;
         if (want < fused_span) fused_span = (uint32_t)want;
     }
     pa.span_lds = want_fused ? fused_span : PR_UNIT;
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+    RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     PlanSummary *hs = (PlanSummary *)g.pin;
     PlanSummary plan;
 
@@ -346,11 +364,11 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
             HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
             // the resident variant only when an average bucket could fit beside the index (~7.4 K tuples)
             if (nmin / bins <= 7000 && !g.no_resident)
-                hipLaunchKernelGGL(k_join_fused<true>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                RHJ_LAUNCH(k_join_fused<true>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             else
-                hipLaunchKernelGGL(k_join_fused<false>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-            hipLaunchKernelGGL(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
-                               (const PlanSummary *)g.summary.p, &((PlanSummary *)g.summary.p)->matches);
+                RHJ_LAUNCH(k_join_fused<false>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            RHJ_LAUNCH(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
+                               (const PlanSummary *)g.summary.p, unit_bound, &((PlanSummary *)g.summary.p)->matches);
             HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
             HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipGetLastError());
@@ -379,7 +397,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         }
         // some bucket needs an HBM table: plan again with tile-granular units
         pa.span_lds = PR_UNIT;
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+        RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
         if (use_ctx_out) { out = nullptr; out_capacity = 0; }
     }
     HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
@@ -395,17 +413,17 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         if (ensure(g.tab64, plan.hbm_slots * 8)) return -1;
         ja.tab64 = (uint64_t *)g.tab64.p;
         HIP_TRY(hipMemsetAsync(g.tab64.p, 0, plan.hbm_slots * 8, g.stream));
-        hipLaunchKernelGGL(k_build_hbm, dim3((unsigned)plan.build_units), dim3(256), 0, g.stream, ja,
+        RHJ_LAUNCH(k_build_hbm, dim3((unsigned)plan.build_units), dim3(256), 0, g.stream, ja,
                            (const Unit *)g.bunits.p);
     }
     if (plan.lds_buckets)
-        hipLaunchKernelGGL(k_build_lds, dim3((unsigned)plan.lds_buckets), dim3(BL_BLOCK), (size_t)plan.max_lds_slots * 4,
+        RHJ_LAUNCH(k_build_lds, dim3((unsigned)plan.lds_buckets), dim3(BL_BLOCK), (size_t)plan.max_lds_slots * 4,
                            g.stream, ja, (const uint32_t *)g.ldsb.p);
 
     const unsigned probe_grid = (unsigned)((plan.units + 7) / 8 * 8);
     HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
     if (plan.units)
-        hipLaunchKernelGGL((k_probe<false>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
+        RHJ_LAUNCH((k_probe<false>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
     HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
     if (launch_offsets((const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
                        (const uint64_t *)&((PlanSummary *)g.summary.p)->units, 0, plan.units,
@@ -429,7 +447,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
     if (plan.units && M && out && out_capacity) {
         ja.out = out; ja.out_capacity = out_capacity;
-        hipLaunchKernelGGL((k_probe<true>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
+        RHJ_LAUNCH((k_probe<true>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
     }
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     HIP_TRY(hipGetLastError());
@@ -471,10 +489,10 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
     }
     uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
     HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
+    RHJ_LAUNCH(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
                        (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
     if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
-    hipLaunchKernelGGL(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
+    RHJ_LAUNCH(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
                        (const uint64_t *)g.fbase.p, d_out);
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));

@@ -1332,10 +1332,12 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 }
 
 // total matches of the fused path = inclusive prefix of the last unit
-__global__ void k_fused_total(const uint64_t *status, const PlanSummary *summary, uint64_t *total_out)
+__global__ void k_fused_total(const uint64_t *status, const PlanSummary *summary, uint64_t unit_bound, uint64_t *total_out)
 {
+    // when the plan rejected the fused path its unit list is the tiled one and can be longer than the
+    // status array: nothing was published, nothing to read
     const uint64_t n = summary->units;
-    *total_out = n ? (status[n - 1] & ((1ull << 62) - 1)) : 0;
+    *total_out = (summary->fused_ok && n && n <= unit_bound) ? (status[n - 1] & ((1ull << 62) - 1)) : 0;
 }
 
 // Exclusive scan of n u64 counts in three launches (n up to ~1M per 1024 block sums):

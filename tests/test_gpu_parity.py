@@ -217,3 +217,27 @@ def test_full_size_properties_c3(rhj):
     bench.check_properties(R, S, t, m, w)
     del R, S, t
     rhj.torch.cuda.empty_cache()
+
+
+def test_first_call_in_fresh_process_takes_the_fallback(oracle):
+    """A fresh process whose FIRST join has buckets too large for LDS (fused kernel launched on the
+    upper-bound grid, plan rejects it, tiled path takes over) — workspace buffers are at their
+    smallest here, which is what exposes out-of-bounds reads that a warmed-up workspace hides."""
+    import subprocess, sys, os
+    code = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+from pyoracle import Oracle
+o = Oracle()
+mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
+rhj.set_bits(4)
+R = o.generate(1200000, 0, 0, 0.0, 5); S = o.generate(900000, 1, 1200000, 0.0, 6)
+t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), capacity=len(S))
+got = rhj.pairs_to_numpy(t); want = o.join(R, S, 4)
+assert m == len(want) and (got == want).all()
+assert rhj.stats()["hbm_units"] > 0          # 64-bit HBM tables were really used
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0 and b"ok" in res.stdout, res.stderr.decode()[-1500:]
