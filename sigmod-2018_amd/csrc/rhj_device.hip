@@ -164,8 +164,8 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
     const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
     const size_t hist_lds = ((size_t)bins + (full_bits ? ((size_t)1 << full_bits) : 0)) * 4;
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), hist_lds, g.stream, r0, r1, shift, bits,
-                       full_bits, (uint32_t *)g.fullhist.p);
+    RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(hist_lds > 32 * 1024 ? 1024 : 256), hist_lds, g.stream, r0, r1,
+               shift, bits, full_bits, (uint32_t *)g.fullhist.p);
     if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
     RHJ_LAUNCH(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (uint64_t *)g.chunk.p);

@@ -161,25 +161,26 @@ constexpr int PT_MAX_BITS = 8;                    // digit bits per pass
 // Per-tile digit histogram of one pass: cnt[tile][digit] for digit = (key >> shift) & mask.
 // full_bits > 0 additionally accumulates the histogram of the low full_bits bits of the
 // key (the join's bucket histogram) into full_hist with one atomic per bin per workgroup.
-__global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits, int full_bits,
+__global__ __launch_bounds__(1024) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits, int full_bits,
                                                     uint32_t *full_hist /*[2][1<<full_bits]*/)
 {
     extern __shared__ uint32_t lds_u32[];
+    const uint32_t nt = blockDim.x;               // 256, or 1024 when the 2^full_bits table limits the CU to 2 workgroups
     const RelArgs &r = blockIdx.y ? r1 : r0;
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     const uint32_t fbins = full_bits ? 1u << full_bits : 0u, fmask = fbins - 1u;
     uint32_t *tile_h = lds_u32;                   // [bins]
     uint32_t *full_h = lds_u32 + bins;            // [fbins]
-    for (uint32_t b = threadIdx.x; b < fbins; b += 256) full_h[b] = 0;
+    for (uint32_t b = threadIdx.x; b < fbins; b += nt) full_h[b] = 0;
     for (uint32_t tile = blockIdx.x; tile < r.tiles; tile += gridDim.x) {
-        for (uint32_t b = threadIdx.x; b < bins; b += 256) tile_h[b] = 0;
+        for (uint32_t b = threadIdx.x; b < bins; b += nt) tile_h[b] = 0;
         __syncthreads();
         const uint64_t beg = (uint64_t)tile * PT_TILE;
         const uint64_t end = min(beg + (uint64_t)PT_TILE, r.n);
         if (r.dig_in) {                               // digits were precomputed by the previous pass: 1 B per tuple
             const uint32_t *d4 = reinterpret_cast<const uint32_t *>(r.dig_in + beg);
             const uint32_t cnt = (uint32_t)(end - beg);
-            for (uint32_t j = threadIdx.x; j < (cnt + 3) / 4; j += 256) {
+            for (uint32_t j = threadIdx.x; j < (cnt + 3) / 4; j += nt) {
                 const uint32_t v = d4[j];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
             }
         } else {
 #pragma unroll 4
-            for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+            for (uint64_t i = beg + threadIdx.x; i < end; i += nt) {
                 const uint32_t k = (uint32_t)r.in[i].value;       // shift + bits and full_bits <= 16
                 atomicAdd(&tile_h[(k >> shift) & mask], 1u);
                 if (full_bits) atomicAdd(&full_h[k & fmask], 1u);
@@ -195,13 +196,13 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
         }
         __syncthreads();
         uint32_t *row = r.cnt + (size_t)tile * bins;
-        for (uint32_t b = threadIdx.x; b < bins; b += 256) row[b] = tile_h[b];
+        for (uint32_t b = threadIdx.x; b < bins; b += nt) row[b] = tile_h[b];
         __syncthreads();
     }
     if (full_bits) {
         __syncthreads();
         uint32_t *dst = full_hist + (size_t)blockIdx.y * fbins;
-        for (uint32_t b = threadIdx.x; b < fbins; b += 256) {
+        for (uint32_t b = threadIdx.x; b < fbins; b += nt) {
             const uint32_t v = full_h[b];
             if (v) atomicAdd(&dst[b], v);
         }
