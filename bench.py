@@ -35,6 +35,7 @@ WORKLOADS = {
     "c2": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="uniform", name="1Mx1M uniform u64 FK, 8 radix bits"),
     "c3": dict(nR=100_000_000, nS=100_000_000, bits=12, dist="uniform", name="100Mx100M uniform u64 FK, 12 radix bits"),
     "c4": dict(nR=100_000_000, nS=1_000_000_000, bits=14, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 14 radix bits (config leaves the radix free: 6.1 K build tuples per bucket fit LDS)"),
+    "c4b15": dict(nR=100_000_000, nS=1_000_000_000, bits=15, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 15 radix bits"),
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
     "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
 }

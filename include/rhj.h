@@ -121,7 +121,7 @@ int               SchedulerDestroy(struct scheduler *sched);
 
 /* ---- knobs the reference hard-codes in structs.h:8-12 -------------------- */
 
-/* N_LSB (structs.h:11), 1..14 here; default 4 or env RHJ_RADIX_BITS.  Returns 0
+/* N_LSB (structs.h:11), 1..15 here; default 4 or env RHJ_RADIX_BITS.  Returns 0
  * or -1 on a value outside the supported range. */
 int  rhj_set_radix_bits(int bits);
 int  rhj_get_radix_bits(void);

@@ -50,7 +50,7 @@ struct Buf {
     size_t cap = 0;
 };
 
-constexpr int MAX_BITS = 14;
+constexpr int MAX_BITS = 15;
 constexpr uint32_t LDS_BUDGET = 160 * 1024;       // bytes per workgroup on gfx950
 
 enum Stage { ST_HIST, ST_SCAN, ST_SCATTER, ST_PLAN, ST_BUILD, ST_COUNT, ST_OFFSETS, ST_PROBE, ST_END, ST_N };
@@ -88,7 +88,7 @@ struct EnvDefaults {
     {
         const char *e;
         if ((e = getenv("RHJ_DEVICE"))) g.device = atoi(e);
-        if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 14) g.bits = b; }
+        if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 15) g.bits = b; }
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
         if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);

@@ -112,7 +112,7 @@ def test_filter_golden(rhj, golden, oracle):
         assert len(d) == c["hits"] and (d == ids).all()
 
 
-@pytest.mark.parametrize("bits", [1, 2, 5, 8, 9, 11, 12, 13, 14])
+@pytest.mark.parametrize("bits", [1, 2, 5, 8, 9, 11, 12, 13, 14, 15])
 def test_partition_matches_oracle(rhj, oracle, bits):
     for n, kind, dom in ((1, 4, 3), (63, 4, 5), (4097, 4, 1 << 30), (300000, 1, 100000), (1000003, 2, 50000)):
         rel = oracle.generate(n, kind, dom, 0.9, 100 + bits)
@@ -127,7 +127,7 @@ def test_partition_matches_oracle(rhj, oracle, bits):
     (3, 1000, 1, 4, 10), (7, 77777, 99999, 1, 50000), (9, 200000, 1000, 4, 1 << 20),
     (12, 2000000, 3000000, 1, 2000000), (12, 100000, 3000000, 2, 100000), (4, 50000, 60000, 4, 11),
     (4, 800000, 900000, 1, 800000), (2, 300000, 500000, 1, 300000),
-    (14, 3000000, 2000000, 1, 3000000), (13, 500000, 4000000, 2, 500000), (14, 100, 5000, 4, 17),
+    (14, 3000000, 2000000, 1, 3000000), (15, 2500000, 3500000, 1, 2500000), (13, 500000, 4000000, 2, 500000), (14, 100, 5000, 4, 17),
     (4, 300000, 350000, 1, 300000), (4, 350000, 300000, 1, 350000), (6, 400000, 400000, 4, 90000),
 ])
 def test_random_joins_vs_oracle(rhj, oracle, bits, nR, nS, kind, dom):

@@ -78,7 +78,7 @@ def test_scheduler_tokens_and_knobs(lib):
     assert lib.SchedulerInit(C.byref(sched), 4) == 0 and sched.value
     assert lib.SchedulerDestroy(sched) == 0
     keep = lib.rhj_get_radix_bits()
-    assert lib.rhj_set_radix_bits(0) == -1 and lib.rhj_set_radix_bits(15) == -1
+    assert lib.rhj_set_radix_bits(0) == -1 and lib.rhj_set_radix_bits(16) == -1
     assert lib.rhj_set_radix_bits(12) == 0 and lib.rhj_get_radix_bits() == 12
     lib.rhj_set_radix_bits(keep)
     assert b"gfx950" in lib.rhj_version()
