@@ -95,6 +95,8 @@ def synthetic_cases():
     add("fk_200k_b1", 1, dict(n=200000, kind=U, seed=71), dict(n=150000, kind=FK, domain=200000, seed=72))
     add("fk_200k_b6", 6, dict(n=200000, kind=U, seed=73), dict(n=250000, kind=FK, domain=200000, seed=74))
     add("fk_200k_b10", 10, dict(n=200000, kind=U, seed=75), dict(n=250000, kind=FK, domain=200000, seed=76))
+    add("fk_300k_b14", 14, dict(n=300000, kind=U, seed=77), dict(n=350000, kind=FK, domain=300000, seed=78))
+    add("dups_300k_b15", 15, dict(n=300000, kind=DUP, domain=90000, seed=79), dict(n=280000, kind=DUP, domain=90000, seed=80))
     add("all_same_key_b4", 4, dict(n=700, kind=DUP, domain=1, seed=1), dict(n=900, kind=DUP, domain=1, seed=2), t4_safe=False)
     out = []
     for c in cases:
