@@ -67,6 +67,7 @@ struct Ctx {
     int         ablate = 0;
     int         no_fused = 0;
     int         no_resident = 0;
+    int         cus = 256;           // compute units of the device (one fused workgroup each)
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
@@ -116,6 +117,8 @@ int ctx_init()
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) { fprintf(stderr, "rhj: no HIP device visible; this library has no CPU path\n"); return -1; }
     HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipDeviceGetAttribute(&g.cus, hipDeviceAttributeMultiprocessorCount, g.device));
+    if (g.cus <= 0) g.cus = 256;
     if (!g.stream_set) { HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true; }
     for (auto &ev : g.ev) HIP_TRY(hipEventCreate(&ev));
     for (auto &ev : g.ev_x) HIP_TRY(hipEventCreate(&ev));
@@ -362,11 +365,13 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
             HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
+            // workgroups are persistent (ticket loop) and the LDS request leaves room for one per CU
+            const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
             // the resident variant only when an average bucket could fit beside the index (~7.4 K tuples)
             if (nmin / bins <= 7000 && !g.no_resident)
-                RHJ_LAUNCH(k_join_fused<true>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                RHJ_LAUNCH(k_join_fused<true>, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             else
-                RHJ_LAUNCH(k_join_fused<false>, dim3((unsigned)unit_bound), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                RHJ_LAUNCH(k_join_fused<false>, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             RHJ_LAUNCH(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
                                (const PlanSummary *)g.summary.p, unit_bound, &((PlanSummary *)g.summary.p)->matches);
             HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));

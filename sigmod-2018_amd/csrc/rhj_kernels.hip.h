@@ -1056,8 +1056,96 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather 
     }
 }
 
+// Exclusive prefix of unit u > 0 in the chained scan (called by ONE wave): sums the predecessors'
+// words 64 at a time until it meets an inclusive prefix; waits only for aggregates, which every unit
+// publishes right after its phase 1.
+__device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t u, uint32_t lane)
+{
+    uint64_t excl = 0;
+    int64_t j = (int64_t)u - 1;
+    for (;;) {
+        const int64_t idx = j - lane;
+        unsigned long long v = 2ull << 62;    // virtual "prefix 0" in front of unit 0
+        if (idx >= 0) {
+            do {
+                v = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2);
+            } while ((v >> 62) == 0);
+        }
+        const uint64_t full = __ballot((v >> 62) == 2);
+        const int stop = full ? __ffsll((unsigned long long)full) - 1 : 64;   // nearest inclusive prefix
+        uint64_t part = lane <= (uint32_t)stop ? (v & ((1ull << 62) - 1)) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        excl += part;
+        if (full) break;
+        j -= 64;
+    }
+    return excl;
+}
+
+// Emit pass of a unit whose probe tuples all have zero or one match and saw no tag collision (so the
+// index is not needed): pure streaming of the stash and the probe row ids, 8 tuples per lane.
+constexpr int FJ_V2 = 8;
+__device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum)
+{
+    const JoinArgs &a = f.j;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const Unit un = a.units[u];
+    const uint32_t b = un.bucket;
+    const bool flip = a.histR[b] < a.histS[b];
+    const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
+    const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
+    const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
+    const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    const uint64_t cap = a.out_capacity;
+    const uint64_t lt = lanemask_lt();
+    uint64_t run = base;
+    for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BLOCK * FJ_V2) {
+        uint32_t c[FJ_V2];
+        uint2 first[FJ_V2], prow[FJ_V2];
+#pragma unroll
+        for (int k = 0; k < FJ_V2; ++k) {
+            const uint32_t i = t0 + w * (WAVE * FJ_V2) + k * WAVE + lane;
+            const bool ok = i < un.count;
+            c[k] = ok ? scnt[i] : 0;
+            first[k] = ok ? srow[i] : make_uint2(0, 0);
+            prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
+        }
+        uint32_t off[FJ_V2], wrun = 0;
+#pragma unroll
+        for (int k = 0; k < FJ_V2; ++k) {
+            const uint64_t m = __ballot(c[k] != 0);
+            off[k] = wrun + (uint32_t)__popcll(m & lt);
+            wrun += (uint32_t)__popcll(m);
+        }
+        __syncthreads();                              // wsum reuse
+        if (lane == 0) wsum[w] = wrun;
+        __syncthreads();
+        uint64_t wbase = run;
+        uint32_t batch_total = 0;
+#pragma unroll
+        for (int i = 0; i < FJ_WAVES; ++i) {
+            const uint32_t v = wsum[i];
+            if ((uint32_t)i < w) wbase += v;
+            batch_total += v;
+        }
+        run += batch_total;
+#pragma unroll
+        for (int k = 0; k < FJ_V2; ++k) {
+            const uint64_t at = wbase + off[k];
+            if (c[k] != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
+        }
+    }
+}
+
 // MAYRES = false compiles the gather path only (the host picks it when the average bucket
 // cannot fit LDS anyway); MAYRES = true decides per unit.
+// A workgroup takes units through the ticket until none is left.  The emit pass of a unit that does
+// not need its index any more (no duplicate match, no tag collision: the common foreign-key case) is
+// DEFERRED behind the next unit's build + phase 1: by then its output base has long been published,
+// so such units never wait on the chain (the wait was 18 % of a unit in the in-kernel stamps).
 template <bool MAYRES>
 __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
 {
@@ -1067,11 +1155,19 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     __shared__ uint32_t wsum[FJ_WAVES];
     const JoinArgs &a = f.j;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long *st = (unsigned long long *)f.status;
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    const uint64_t cap = a.out_capacity;
+    const bool emitting = out != nullptr && a.ablate != 3;
+    uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
+    uint64_t pend_total = 0;
 
+    for (;;) {
+    __syncthreads();
     if (threadIdx.x == 0) sh_u = atomicAdd(f.ticket, 1u);
     __syncthreads();
     const uint32_t u = sh_u;
-    if (u >= a.summary->units || !a.summary->fused_ok) return;        // grid is an upper bound; tiled path takes over
+    if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
     const uint64_t cR = a.histR[b], cS = a.histS[b];
@@ -1135,11 +1231,12 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         }
     }
     __syncthreads();
-    if (a.ablate == 1) return;                        // timing experiment: build only
+    if (a.ablate == 1) continue;                      // timing experiment: build only
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
     uint32_t mine = 0;
+    bool needs_index = false;                         // some tuple has duplicates or a tag collision
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
         uint4 q[FJ_V];
         bool okk[FJ_V];
@@ -1163,6 +1260,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 reinterpret_cast<uint2 *>(srow)[i] = make_uint2(flo[k], fhi[k]);
             }
             mine += c[k];
+            needs_index = needs_index || c[k] >= 2u || fp[k];
         }
     }
 
@@ -1173,50 +1271,50 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         wave_excl_scan_u32(mine, &tot);
         if (lane == 0) wsum[w] = tot;
     }
-    __syncthreads();
-    if (w == 0) {
-        uint64_t total = 0;
-        for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
-        unsigned long long *st = (unsigned long long *)f.status;
-        uint64_t excl = 0;
-        if (u == 0) {
-            if (lane == 0) __hip_atomic_store(&st[0], (2ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(&st[u], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int64_t j = (int64_t)u - 1;               // look back 64 predecessors at a time
-            for (;;) {
-                const int64_t idx = j - lane;
-                unsigned long long v = 2ull << 62;    // virtual "prefix 0" in front of unit 0
-                if (idx >= 0) {
-                    do {
-                        v = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2);
-                    } while ((v >> 62) == 0);
-                }
-                const uint64_t full = __ballot((v >> 62) == 2);
-                const int stop = full ? __ffsll((unsigned long long)full) - 1 : 64;   // nearest inclusive prefix
-                uint64_t part = lane <= (uint32_t)stop ? (v & ((1ull << 62) - 1)) : 0;
+    const bool unit_needs_index = __syncthreads_or(needs_index) != 0;   // also publishes wsum
+    uint64_t total = 0;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-                excl += part;
-                if (full) break;
-                j -= 64;
+    for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
+    if (threadIdx.x == 0) {
+        // aggregate first: successors only ever wait for this word
+        __hip_atomic_store(&st[u], ((u == 0 ? 2ull : 1ull) << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.unit_count[u] = total;
+    }
+
+    // ---- the deferred emit pass of the previous unit, whose base is certainly known by now
+    if (pend != 0xffffffffu) {
+        if (w == 0) {
+            const uint64_t excl = pend == 0 ? 0 : fj_lookback(st, pend, lane);
+            if (lane == 0) {
+                if (pend != 0) __hip_atomic_store(&st[pend], (2ull << 62) | (excl + pend_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_base = excl;
             }
-            if (lane == 0) __hip_atomic_store(&st[u], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __syncthreads();
+        fj_emit_stream(f, pend, sh_base, wsum);
+        pend = 0xffffffffu;
+        __syncthreads();
+    }
+    if (emitting && !RES && !unit_needs_index) {      // this unit's emit pass needs no index: defer it
+        pend = u;
+        pend_total = total;
+        if (f.dbg && threadIdx.x == 0) { f.dbg[(size_t)u * 8 + 3] = f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
+        continue;
+    }
+
+    if (w == 0) {
+        const uint64_t excl = u == 0 ? 0 : fj_lookback(st, u, lane);
         if (lane == 0) {
+            if (u != 0) __hip_atomic_store(&st[u], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sh_base = excl;
-            a.unit_count[u] = total;
         }
     }
     __syncthreads();
 
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    // ---- phase 2: emit
+    // ---- phase 2: emit (general form: duplicates and tag collisions walk the index again)
     uint64_t run = sh_base;
-    const uint64_t cap = a.out_capacity;
-    uint4 *out = reinterpret_cast<uint4 *>(a.out);
-    if (out == nullptr || a.ablate == 3) return;
+    if (!emitting) continue;
     // FJ_H batches per iteration; a wave's slice of the iteration is contiguous: order (wave, half,
     // round, lane).  FJ_H = 2 (more loads in flight, half the barriers) measured +11 % on the kernel:
     // it spills at the 128-VGPR limit of a 1024-thread workgroup.
@@ -1330,6 +1428,20 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         }
     }
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    }   // ticket loop
+
+    if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup
+        __syncthreads();
+        if (w == 0) {
+            const uint64_t excl = pend == 0 ? 0 : fj_lookback(st, pend, lane);
+            if (lane == 0) {
+                if (pend != 0) __hip_atomic_store(&st[pend], (2ull << 62) | (excl + pend_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_base = excl;
+            }
+        }
+        __syncthreads();
+        fj_emit_stream(f, pend, sh_base, wsum);
+    }
 }
 
 // total matches of the fused path = inclusive prefix of the last unit
