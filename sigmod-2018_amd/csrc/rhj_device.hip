@@ -72,7 +72,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_out[2] = {nullptr, nullptr};   // D2H staging of result pairs
@@ -335,7 +335,8 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         // does not fit LDS (then the tiled path below takes over).  One host sync per join.
         const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;
         if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
-            ensure(g.status, (unit_bound + 1) * 8 + 64))
+            ensure(g.status, (unit_bound + 1) * 8 + 64) ||
+            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
             return -1;
         FusedArgs fa;
         fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
@@ -344,6 +345,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         fa.nR = nR;
         fa.allow_resident = !g.no_resident; fa.pad = 0;
         fa.dbg = nullptr;
+        fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p;
         if (getenv("RHJ_STAMPS")) {                           // diagnostic runs only
             if (ensure(g.dbg, (unit_bound + 1) * 64)) return -1;
             fa.dbg = (uint64_t *)g.dbg.p;
@@ -609,7 +611,7 @@ void rhj_release(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);

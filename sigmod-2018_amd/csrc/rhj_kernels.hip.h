@@ -914,6 +914,9 @@ constexpr int FJ_V = 4;
 constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
 constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
 constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
+constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
+constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
+constexpr uint32_t FJ_GROUPS = FJ_SPAN / 256;   // a group = the 256 tuples one wave counts in one batch
 
 struct FusedArgs {
     JoinArgs  j;
@@ -925,6 +928,8 @@ struct FusedArgs {
     uint32_t  allow_resident;
     uint32_t  pad;
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
+    uint64_t *ovf;            // [grid][2][FJ_OVF_CAP] build row ids of second and later matches (per workgroup, double-buffered)
+    uint32_t *ovf_base;       // [grid][2][FJ_SPAN / 256][16] first overflow slot of (256-tuple group, match ordinal)
 };
 
 
@@ -1024,10 +1029,26 @@ struct FjGather {
     }
 };
 
-template <bool RES>
+// Overflow stash of the gather path.  Phase 1 has every match's build row id in registers at the
+// moment it verifies it, so besides the first one (stash_row) it keeps the others too: a wave that
+// finds second-or-later matches in round r (r = 1, 2, ...; a tuple whose tag hits are all matches
+// finds its (r+1)-th match exactly there) takes a contiguous run of slots with one LDS atomic, records
+// the run's start for (its 256-tuple group, r) and stores the row ids in (k, lane) order.  The emit
+// pass recomputes the same ranks from the stashed counts, so it needs neither the index nor a gather
+// and can run any time later.  Tuples that break the rule (a tag hit with a foreign key next to two or
+// more matches, more than 16 matches, capacity) make the unit fall back to the index walk.
+struct FjOvf {
+    uint64_t *buf;        // this unit's overflow entries
+    uint32_t *table;      // this unit's [group][16] run starts
+    uint32_t *counter;    // LDS bump counter
+    uint32_t  gid;        // group of this wave in this batch
+};
+
+template <bool RES, bool OVF>
 __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather &G, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
-                                               uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V])
+                                               uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
+                                               const FjOvf &O)
 {
     uint32_t cur[FJ_V], tg[FJ_V];
 #pragma unroll
@@ -1037,7 +1058,7 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather 
         cur[k] = okk[k] ? X.head(X.slot(h)) : 0;
         c[k] = 0; flo[k] = 0; fhi[k] = 0; fp[k] = false;
     }
-    for (;;) {
+    for (uint32_t round = 0;; ++round) {
         uint32_t pos[FJ_V];
         if (!fj_walk_round(X, cur, tg, pos)) break;
         uint4 g[FJ_V];
@@ -1046,12 +1067,37 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather 
             g[k] = make_uint4(0, 0, 0, 0);
             if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : G.load(pos[k]);
         }
+        bool ex[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
             if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
+            ex[k] = OVF && eq && c[k] != 0;
             c[k] += eq;
             fp[k] = fp[k] || (pos[k] != 0xffffffffu && !eq);      // a tag hit with a different key
+        }
+        if (OVF && round != 0) {
+            uint64_t mk[FJ_V];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) { mk[k] = __ballot(ex[k]); tot += (uint32_t)__popcll(mk[k]); }
+            if (tot != 0) {
+                const uint32_t lane = threadIdx.x & 63;
+                const uint64_t lt = lanemask_lt();
+                uint32_t base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(O.counter, tot);
+                    if (round <= FJ_OVF_J) O.table[O.gid * 16u + round] = base;
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                uint32_t pre = base;
+#pragma unroll
+                for (int k = 0; k < FJ_V; ++k) {
+                    const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
+                    if (ex[k] && slot < FJ_OVF_CAP) reinterpret_cast<uint2 *>(O.buf)[slot] = make_uint2(g[k].z, g[k].w);
+                    pre += (uint32_t)__popcll(mk[k]);
+                }
+            }
         }
     }
 }
@@ -1084,11 +1130,14 @@ __device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t
     return excl;
 }
 
-// Emit pass of a unit whose probe tuples all have zero or one match and saw no tag collision (so the
-// index is not needed): pure streaming of the stash and the probe row ids, 8 tuples per lane.
-constexpr int FJ_V2 = 8;
-__device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum)
+// Deferred emit pass of a gather-path unit: pure streaming of the probe row ids, the stash and (DUP)
+// the overflow stash, 8 tuples per lane; the index is not needed.  DUP = false: every probe tuple has
+// zero or one match (the foreign-key case), offsets come from ballots.
+template <bool DUP>
+__device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum,
+                                               const uint64_t *ovf, uint32_t *table)
 {
+    constexpr int V = FJ_V;                           // a wave's step is one 256-tuple group of phase 1
     const JoinArgs &a = f.j;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const Unit un = a.units[u];
@@ -1101,41 +1150,91 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const uint64_t cap = a.out_capacity;
     const uint64_t lt = lanemask_lt();
-    uint64_t run = base;
-    for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BLOCK * FJ_V2) {
-        uint32_t c[FJ_V2];
-        uint2 first[FJ_V2], prow[FJ_V2];
+    const uint32_t ngroups = (un.count + 255u) >> 8;
+
+    // group totals (phase 1 left them in column 0 of the table) -> exclusive starts, once per unit;
+    // after that the waves run without any barrier
+    {
+        const uint32_t t = threadIdx.x;
+        uint32_t v = 0;
+        if (t < ngroups) v = __hip_atomic_load(&table[t * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t tot;
+        uint32_t ex = wave_excl_scan_u32(v, &tot);
+        __syncthreads();                              // wsum reuse
+        if (lane == 0) wsum[w] = tot;
+        __syncthreads();
+        for (uint32_t i = 0; i < w && i < FJ_GROUPS / WAVE; ++i) ex += wsum[i];
+        if (t < ngroups) __hip_atomic_store(&table[t * 16u], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+    }
+
+    for (uint32_t g = w; g < ngroups; g += FJ_WAVES) {
+        uint32_t c[V];
+        uint2 first[V], prow[V];
 #pragma unroll
-        for (int k = 0; k < FJ_V2; ++k) {
-            const uint32_t i = t0 + w * (WAVE * FJ_V2) + k * WAVE + lane;
+        for (int k = 0; k < V; ++k) {
+            const uint32_t i = g * 256u + k * WAVE + lane;
             const bool ok = i < un.count;
-            c[k] = ok ? scnt[i] : 0;
+            c[k] = ok ? (scnt[i] & 0x7fu) : 0;
             first[k] = ok ? srow[i] : make_uint2(0, 0);
             prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
         }
-        uint32_t off[FJ_V2], wrun = 0;
+        // the group's table row: lane 0 its start in the unit's output, lane j the run start of ordinal j
+        uint32_t tbl_v = 0;
+        if (lane < 16) tbl_v = __hip_atomic_load(&table[g * 16u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t off[V], wrun = 0;
 #pragma unroll
-        for (int k = 0; k < FJ_V2; ++k) {
-            const uint64_t m = __ballot(c[k] != 0);
-            off[k] = wrun + (uint32_t)__popcll(m & lt);
-            wrun += (uint32_t)__popcll(m);
+        for (int k = 0; k < V; ++k) {
+            if (DUP) {
+                uint32_t tot;
+                off[k] = wrun + wave_excl_scan_u32(c[k], &tot);
+                wrun += tot;
+            } else {
+                const uint64_t m = __ballot(c[k] != 0);
+                off[k] = wrun + (uint32_t)__popcll(m & lt);
+                wrun += (uint32_t)__popcll(m);
+            }
         }
-        __syncthreads();                              // wsum reuse
-        if (lane == 0) wsum[w] = wrun;
-        __syncthreads();
-        uint64_t wbase = run;
-        uint32_t batch_total = 0;
+        const uint64_t wbase = base + (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, 0);
 #pragma unroll
-        for (int i = 0; i < FJ_WAVES; ++i) {
-            const uint32_t v = wsum[i];
-            if ((uint32_t)i < w) wbase += v;
-            batch_total += v;
-        }
-        run += batch_total;
-#pragma unroll
-        for (int k = 0; k < FJ_V2; ++k) {
+        for (int k = 0; k < V; ++k) {
             const uint64_t at = wbase + off[k];
             if (c[k] != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
+        }
+        if (DUP) {
+            // second and later matches: ordinal j of the group's tuples sits in one run of the overflow
+            // stash, in (k, lane) order (fj_count_batch).  Four ordinals per step, loads before stores.
+            for (uint32_t j0 = 1;; j0 += 4) {
+                uint2 r[4][V];
+                bool any = false;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t j = j0 + jj;
+                    uint64_t mk[V];
+                    uint32_t tot = 0;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) { mk[k] = __ballot(c[k] > j); tot += (uint32_t)__popcll(mk[k]); }
+                    any = any || tot != 0;
+                    uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, (int)(j & 15u));
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
+                        r[jj][k] = make_uint2(0, 0);
+                        if (c[k] > j) r[jj][k] = reinterpret_cast<const uint2 *>(ovf)[slot];
+                        pre += (uint32_t)__popcll(mk[k]);
+                    }
+                }
+                if (!any) break;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const uint64_t at = wbase + off[k] + j0 + jj;
+                        if (c[k] > j0 + jj && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, r[jj][k].x, r[jj][k].y);
+                    }
+                }
+                if (j0 + 4 > FJ_OVF_J) break;
+            }
         }
     }
 }
@@ -1143,7 +1242,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
 // MAYRES = false compiles the gather path only (the host picks it when the average bucket
 // cannot fit LDS anyway); MAYRES = true decides per unit.
 // A workgroup takes units through the ticket until none is left.  The emit pass of a unit that does
-// not need its index any more (no duplicate match, no tag collision: the common foreign-key case) is
+// not need its index any more (no probe tuple with two or more matches: the foreign-key case) is
 // DEFERRED behind the next unit's build + phase 1: by then its output base has long been published,
 // so such units never wait on the chain (the wait was 18 % of a unit in the in-kernel stamps).
 template <bool MAYRES>
@@ -1151,6 +1250,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
     __shared__ uint32_t sh_u;
+    __shared__ uint32_t sh_ovf;
     __shared__ uint64_t sh_base;
     __shared__ uint32_t wsum[FJ_WAVES];
     const JoinArgs &a = f.j;
@@ -1161,10 +1261,13 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     const bool emitting = out != nullptr && a.ablate != 3;
     uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
     uint64_t pend_total = 0;
+    bool pend_dup = false;
+    const uint64_t *pend_ovf = nullptr;
+    uint32_t *pend_table = nullptr;
 
-    for (;;) {
+    for (uint32_t iter = 0;; ++iter) {
     __syncthreads();
-    if (threadIdx.x == 0) sh_u = atomicAdd(f.ticket, 1u);
+    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; }
     __syncthreads();
     const uint32_t u = sh_u;
     if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
@@ -1198,6 +1301,11 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
     FjGather G;
     G.init(bd, bc);
+    FjOvf O;                                          // double-buffered: the previous unit's emit may still be pending
+    O.buf = f.ovf + ((size_t)blockIdx.x * 2 + (iter & 1u)) * FJ_OVF_CAP;
+    O.table = f.ovf_base + ((size_t)blockIdx.x * 2 + (iter & 1u)) * (FJ_GROUPS * 16u);
+    O.counter = &sh_ovf;
+    O.gid = 0;
 
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
@@ -1236,7 +1344,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 
     // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
     uint32_t mine = 0;
-    bool needs_index = false;                         // some tuple has duplicates or a tag collision
+    bool needs_index = false;                         // the emit pass must walk the index again
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
         uint4 q[FJ_V];
         bool okk[FJ_V];
@@ -1248,8 +1356,9 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             okk[k] = i < un.count;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
-        if (RES) fj_count_batch<true>(X, G, ltup, q, okk, c, flo, fhi, fp);
-        else     fj_count_batch<false>(X, G, ltup, q, okk, c, flo, fhi, fp);
+        O.gid = (t0 >> 8) + w;
+        if (RES) fj_count_batch<true, false>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        else     fj_count_batch<false, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
@@ -1260,18 +1369,25 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 reinterpret_cast<uint2 *>(srow)[i] = make_uint2(flo[k], fhi[k]);
             }
             mine += c[k];
-            needs_index = needs_index || c[k] >= 2u || fp[k];
+            needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
+        }
+        if (!RES) {                                   // group total for the barrier-free emit pass
+            uint32_t gt;
+            wave_excl_scan_u32(c[0] + c[1] + c[2] + c[3], &gt);
+            if (lane == 0) O.table[O.gid * 16u] = gt;
         }
     }
 
     // ---- unit total -> chained scan
-    if (f.dbg && lane == 0) { if (w == 0) f.dbg[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); if (w == FJ_WAVES - 1) f.dbg[(size_t)u * 8 + 5] = __builtin_amdgcn_s_memrealtime(); }
+    if (f.dbg && lane == 0) { if (w == 0) f.dbg[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
     {
         uint32_t tot;
         wave_excl_scan_u32(mine, &tot);
         if (lane == 0) wsum[w] = tot;
     }
-    const bool unit_needs_index = __syncthreads_or(needs_index) != 0;   // also publishes wsum
+    bool unit_needs_index = __syncthreads_or(needs_index) != 0;   // also publishes wsum
+    const uint32_t ovf_total = sh_ovf;
+    unit_needs_index = unit_needs_index || ovf_total > FJ_OVF_CAP;
     uint64_t total = 0;
 #pragma unroll
     for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
@@ -1291,13 +1407,18 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         __syncthreads();
-        fj_emit_stream(f, pend, sh_base, wsum);
+        if (pend_dup) fj_emit_stream<true>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        else          fj_emit_stream<false>(f, pend, sh_base, wsum, pend_ovf, pend_table);
         pend = 0xffffffffu;
         __syncthreads();
     }
+    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 6] = (unit_needs_index ? 1u : 0u) | (RES ? 2u : 0u) | (emitting ? 4u : 0u) | ((uint64_t)total << 8);
     if (emitting && !RES && !unit_needs_index) {      // this unit's emit pass needs no index: defer it
         pend = u;
         pend_total = total;
+        pend_dup = ovf_total != 0;
+        pend_ovf = O.buf;
+        pend_table = O.table;
         if (f.dbg && threadIdx.x == 0) { f.dbg[(size_t)u * 8 + 3] = f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
         continue;
     }
@@ -1319,6 +1440,10 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     // round, lane).  FJ_H = 2 (more loads in flight, half the barriers) measured +11 % on the kernel:
     // it spills at the 128-VGPR limit of a 1024-thread workgroup.
     constexpr int FJ_H = 1;
+    uint32_t dt_load = 0, dt_scan = 0, dt_walk = 0;
+    uint64_t tm = 0;
+#define FJ_STAMP(acc) if (f.dbg) { __builtin_amdgcn_s_waitcnt(0); const uint64_t now_ = __builtin_amdgcn_s_memrealtime(); acc += (uint32_t)(now_ - tm); tm = now_; }
+    if (f.dbg) tm = __builtin_amdgcn_s_memrealtime();
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_H * FJ_BATCH) {
         uint32_t c[FJ_H][FJ_V], flo[FJ_H][FJ_V], fhi[FJ_H][FJ_V];
         uint4 q[FJ_H][FJ_V];
@@ -1343,7 +1468,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 #pragma unroll
         for (int h = 0; h < FJ_H; ++h) {
             if (RES) {
-                fj_count_batch<true>(X, G, ltup, q[h], okk[h], c[h], flo[h], fhi[h], fpt[h]);   // LDS only: cheaper than a stash round trip
+                fj_count_batch<true, false>(X, G, ltup, q[h], okk[h], c[h], flo[h], fhi[h], fpt[h], O);   // LDS only: cheaper than a stash round trip
             } else {
                 // saturated counts: recount from the index (also yields the exact number to emit)
 #pragma unroll
@@ -1362,6 +1487,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 }
             }
         }
+        FJ_STAMP(dt_load)
         uint32_t off[FJ_H][FJ_V], wrun = 0;
 #pragma unroll
         for (int h = 0; h < FJ_H; ++h) {
@@ -1384,6 +1510,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             batch_total += v;
         }
         run += batch_total;
+        FJ_STAMP(dt_scan)
         // The first match comes from the stash (phase 1 kept its row id).  Further matches of a tuple
         // are fetched in lockstep rounds over its chain; when no tag hit of the tuple was a foreign key
         // (the rule: stash bit 7 clear) its first candidate IS that first match and is skipped unfetched.
@@ -1426,8 +1553,10 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 }
             }
         }
+        FJ_STAMP(dt_walk)
     }
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (f.dbg && threadIdx.x == 64) { f.dbg[(size_t)u * 8 + 7] = ((uint64_t)dt_load << 32) | dt_scan; f.dbg[(size_t)u * 8 + 5] = dt_walk; }
     }   // ticket loop
 
     if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup
@@ -1440,7 +1569,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         __syncthreads();
-        fj_emit_stream(f, pend, sh_base, wsum);
+        if (pend_dup) fj_emit_stream<true>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        else          fj_emit_stream<false>(f, pend, sh_base, wsum, pend_ovf, pend_table);
     }
 }
 

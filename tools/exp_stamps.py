@@ -33,3 +33,16 @@ for name, col, hi in (("p1 load", 6, True), ("p1 walk", 6, False), ("p1 gather",
     v = (buf[:, col] >> np.uint64(32)) if hi else (buf[:, col] & np.uint64(0xffffffff))
     d = us(v.astype(np.int64))
     print("%-28s mean %.1f  p50 %.1f  max %.1f us (wave 1, drained at every stamp)" % (name, d.mean(), np.median(d), d.max()))
+
+flags = buf[:, 6] & np.uint64(0xff)
+print("flag histogram (1 needs_index, 2 RES, 4 emitting):", np.unique(flags, return_counts=True))
+print("unit totals:", (buf[:8, 6] >> np.uint64(8)))
+
+gen = (flags & np.uint64(1)) != 0
+for name, v in (("p2 load+stash", buf[:, 7] >> np.uint64(32)), ("p2 scan+barriers", buf[:, 7] & np.uint64(0xffffffff)), ("p2 stores+walk", buf[:, 5])):
+    d = us(v.astype(np.int64))[gen]
+    print("general phase 2, wave 1: %-18s mean %.1f p50 %.1f max %.1f us" % (name, d.mean(), np.median(d), d.max()))
+for sel, nm in ((gen, "dup units"), (~gen, "fk units")):
+    for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("2->3", 2, 3), ("phase2", 3, 4)):
+        d = us(t[:, b] - t[:, a])[sel]
+        print("%s %-12s mean %.1f p50 %.1f" % (nm, name, d.mean(), np.median(d)))
