@@ -286,7 +286,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     const bool want_fused = !g.no_fused && !g.force_hbm;
     const uint32_t lds_max_slots = LDS_BUDGET / 4 / 4 * 4;                 // tiled path: k_build_lds owns the whole LDS
     uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
-    if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 64) * 2 / 9;    // fused: 4 B node + >= 0.5 B of head links per build tuple
+    if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 128) * 2 / 9;   // fused: 4 B entry + >= 0.5 B of slot starts per build tuple
     if (lds_cap > 65534) lds_cap = 65534;                                  // 16-bit position + 1
     if (g.force_hbm) lds_cap = 0;
     const uint64_t nmin = nR < nS ? nR : nS;

@@ -933,74 +933,229 @@ struct FusedArgs {
 };
 
 
-// LDS index of the fused kernel: sorted chains.
-//   node[i]  (i = build position in the bucket)  = tag16 << 16 | next   (next = position + 1, 0 = end)
-//   head16[] one 16-bit link per hash slot (two per 32-bit word), slots = build count
-// A chain lists the build positions that hash to its slot in DESCENDING order — exactly the
-// reference's bucket/chain index (CreateIndex walks last->first and appends at the tail,
-// rhjoin.c:219-250) — built here by lock-free sorted insertion (32-bit CAS on the word that
-// holds the 16-bit link), so the structure is the same for every interleaving.  Unlike
-// linear probing there is no clustering: a walk is as long as its chain (Poisson, max ~7 at
-// load 1), and the FJ_V tuples of a lane walk their chains in lockstep.
+// LDS index of the fused kernel: the build positions of a bucket grouped by hash slot (CSR).
+//   ent[p]   tag16 << 16 | build position, the entries of one slot contiguous and in DESCENDING value
+//            order.  Equal keys have equal tags, so the positions of one key come out descending —
+//            the order in which the reference's bucket/chain index hands out the matches of a key
+//            (CreateIndex walks last->first and appends at the tail, rhjoin.c:219-250).  Tags are
+//            1..0xfffe: 0 is the empty cell during the build, 0xffff the 8 pad entries behind the array.
+//   H[s + 1] 16-bit start of slot s in ent[], H[s + 2] its end (two per 32-bit word)
+// Built by a counting sort in LDS: count per slot, exclusive scan, then every tuple enters its slot's
+// range by ordered insertion (atomicMax on the cell, carry the smaller value to the next cell: the
+// range ends up sorted for every interleaving, like the chains this replaces).  A probe reads the
+// slot's start and end and a window of 8 entries, compares the 8 tags at once and keeps a bit mask of
+// the hits: no pointer chasing and no loop whose trip count is the longest chain of the wave (the
+// linked chains spent 2/3 of the probe's vector instructions there).  Slots longer than 8 continue
+// window by window.
 struct FjIndex {
-    uint32_t *node;      // [bc]
-    uint32_t *headw;     // [(hs + 1) / 2] two 16-bit links per word
+    uint32_t *ent;       // [bc + 8]
+    uint32_t *dirw;      // [(hs + 3) / 2]
     uint32_t  hs;
     __device__ __forceinline__ uint32_t slot(uint64_t h) const { return __umulhi((uint32_t)(h >> 32), hs); }
-    __device__ __forceinline__ uint32_t head(uint32_t sl) const
-    {
-        const uint32_t wv = headw[sl >> 1];
-        return (sl & 1u) ? wv >> 16 : wv & 0xffffu;
-    }
+    __device__ __forceinline__ uint32_t H(uint32_t j) const { return reinterpret_cast<const uint16_t *>(dirw)[j]; }
 };
+__device__ __forceinline__ uint32_t fj_tag(uint64_t h) { return min((uint32_t)(h >> 16) & 0xffffu, 0xfffdu) + 1u; }
 
-__device__ __forceinline__ void fj_insert(const FjIndex &X, uint64_t key, uint32_t i)
+// hit mask of the first min(n, 8) entries of the window at `start`
+__device__ __forceinline__ uint32_t fj_window(const FjIndex &X, uint32_t start, uint32_t n, uint32_t tgs)
 {
-    const uint64_t h = mix64(key);
-    const uint32_t sl = X.slot(h);
-    const uint32_t tagw = t32_tag(h) << 16;
-    bool at_head = true;
-    uint32_t prev = 0;                                   // node index when !at_head
-    for (;;) {
-        uint32_t word, cur;
-        if (at_head) { word = X.headw[sl >> 1]; cur = (sl & 1u) ? word >> 16 : word & 0xffffu; }
-        else         { word = X.node[prev];     cur = word & 0xffffu; }
-        if (cur != 0 && cur - 1u > i) { at_head = false; prev = cur - 1u; continue; }   // keep descending order
-        X.node[i] = tagw | cur;                          // complete before it becomes reachable
-        uint32_t want;
-        if (at_head) want = (sl & 1u) ? (word & 0xffffu) | ((i + 1u) << 16) : (word & 0xffff0000u) | (i + 1u);
-        else         want = (word & 0xffff0000u) | (i + 1u);
-        uint32_t *addr = at_head ? &X.headw[sl >> 1] : &X.node[prev];
-        if (atomicCAS(addr, word, want) == word) break;  // else: the link (or its word neighbour) moved, look again
-    }
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = X.ent[start + j];
+    const uint32_t tg = tgs >> 16;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m |= ((e[j] >> 16) == tg) ? (1u << j) : 0u;
+    return m & ((1u << min(n, 8u)) - 1u);
 }
 
-// One round of the probe walk: every tuple with a live cursor follows its chain to the next
-// node that carries its tag (pos[k]) or to the end (cursor 0).  Returns whether any lane of
-// the wave found a candidate.
-__device__ __forceinline__ bool fj_walk_round(const FjIndex &X, uint32_t (&cur)[FJ_V], const uint32_t (&tg)[FJ_V],
-                                              uint32_t (&pos)[FJ_V])
+// Per probe tuple: sn = window start | remaining slot length << 16, tm = tag << 16 | hit mask of the
+// current window.
+__device__ __forceinline__ void fj_lookup(const FjIndex &X, uint64_t key, bool ok, uint32_t &sn, uint32_t &tm)
 {
-    bool found = false;
+    const uint64_t h = mix64(key);
+    const uint32_t s = X.slot(h);
+    const uint32_t d0 = X.H(s + 1u), n = ok ? X.H(s + 2u) - d0 : 0u;
+    const uint32_t tgs = fj_tag(h) << 16;
+    sn = d0 | (n << 16);
+    tm = tgs | fj_window(X, d0, n, tgs);
+}
+
+// One round of the probe: every tuple that still has a candidate hands out its next one (pos[k], a
+// build position) — first from the window's hit mask, and when that is used up and the slot is longer
+// than the window, from the next window.  Returns whether any lane of the wave got a candidate.
+__device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V], uint32_t (&tm)[FJ_V], uint32_t (&pos)[FJ_V],
+                                         bool &last)
+{
+    bool more = false;
 #pragma unroll
-    for (int k = 0; k < FJ_V; ++k) pos[k] = 0xffffffffu;
-    for (;;) {
-        uint32_t n[FJ_V];
-#pragma unroll
-        for (int k = 0; k < FJ_V; ++k)
-            n[k] = (cur[k] != 0 && pos[k] == 0xffffffffu) ? X.node[cur[k] - 1u] : 0;
-        bool again = false;
+    for (int k = 0; k < FJ_V; ++k) more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u);
+    while (__ballot(more) != 0) {                     // rare: a slot with more than 8 entries
+        more = false;
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
-            if (cur[k] != 0 && pos[k] == 0xffffffffu) {
-                if ((n[k] >> 16) == tg[k]) { pos[k] = cur[k] - 1u; found = true; }
-                cur[k] = n[k] & 0xffffu;
-                again = again || (pos[k] == 0xffffffffu && cur[k] != 0);
+            if ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u) {
+                sn[k] += 8u - (8u << 16);             // start += 8, length -= 8
+                tm[k] |= fj_window(X, sn[k] & 0xffffu, sn[k] >> 16, tm[k] & 0xffff0000u);
+                more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u);
             }
         }
-        if (__ballot(again) == 0) break;
     }
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        pos[k] = 0xffffffffu;
+        const uint32_t m = tm[k] & 0xffu;
+        if (m != 0) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            pos[k] = X.ent[(sn[k] & 0xffffu) + j] & 0xffffu;
+            tm[k] &= tm[k] - 1u;                      // the mask sits in the low bits
+            found = true;
+        }
+    }
+    bool rest = false;                                // spares the caller a round that finds nothing
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) rest = rest || (tm[k] & 0xffu) != 0 || (sn[k] >> 16) > 8u;
+    last = __ballot(rest) == 0;
     return __ballot(found) != 0;
+}
+
+// Build the index of one bucket's build side (whole workgroup).  RES: the tuples are copied to LDS
+// on the way and the second pass reads them there.  `tmp` is global scratch of at least 4 * bc bytes
+// for the cooperative sort of long slots.
+constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
+template <bool RES>
+__device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, uint32_t bc, uint4 *ltup,
+                                         uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick, uint64_t *dbgu)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
+    const uint32_t ndw = (X.hs + 3u) / 2u;
+    for (uint32_t i = tid; i < ndw; i += FJ_BLOCK) X.dirw[i] = 0;
+    for (uint32_t i = tid; i < bc; i += FJ_BLOCK) X.ent[i] = 0;
+    if (tid < 8) X.ent[bc + tid] = 0xffff0000u;
+    __syncthreads();
+    // ---- count: H[s + 1] += 1
+    {
+        uint4 t[FJ_V], tn[FJ_V];                       // current and prefetched batch of build tuples
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = k * FJ_BLOCK + tid;
+            t[k] = make_uint4(0, 0, 0, 0);
+            if (i < bc) { if (RES) t[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; t[k].x = kv.x; t[k].y = kv.y; } }
+        }
+        for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {               // next batch's loads fly while this batch is counted
+                const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + tid;
+                tn[k] = make_uint4(0, 0, 0, 0);
+                if (i < bc) { if (RES) tn[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; tn[k].x = kv.x; tn[k].y = kv.y; } }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = i0 + k * FJ_BLOCK + tid;
+                if (i < bc) {
+                    if (RES) ltup[i] = t[k];
+                    const uint32_t j = X.slot(mix64(((uint64_t)t[k].y << 32) | t[k].x)) + 1u;
+                    atomicAdd(&X.dirw[j >> 1], (j & 1u) ? 0x10000u : 1u);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) t[k] = tn[k];
+        }
+    }
+    __syncthreads();
+    if (dbgu && threadIdx.x == 0) dbgu[5] = __builtin_amdgcn_s_memrealtime();
+    // ---- exclusive scan over the halfwords: H[s + 1] = start of slot s, H[hs + 1] = bc
+    {
+        const uint32_t chunk = (ndw + FJ_BLOCK - 1u) / FJ_BLOCK;
+        const uint32_t lo = min(tid * chunk, ndw), hi = min(lo + chunk, ndw);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = X.dirw[i]; sum += (v & 0xffffu) + (v >> 16); }
+        uint32_t tot;
+        uint32_t run = wave_excl_scan_u32(sum, &tot);
+        if (lane == 0) wsum[w] = tot;
+        __syncthreads();
+        for (uint32_t i = 0; i < w; ++i) run += wsum[i];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t v = X.dirw[i];
+            const uint32_t a0 = run; run += v & 0xffffu;
+            const uint32_t a1 = run; run += v >> 16;
+            X.dirw[i] = a0 | (a1 << 16);
+        }
+    }
+    __syncthreads();
+    if (dbgu && threadIdx.x == 0) dbgu[6] = __builtin_amdgcn_s_memrealtime();
+    // ---- fill.  Ordered insertion into the slot's range: atomicMax on the cell, go on with the
+    // smaller of the two values; exactly n values enter n cells, so a carry always finds an empty cell
+    // inside the range.  Long slots (many duplicates of one key, where that would be quadratic) take
+    // places in arrival order — the range's last cell counts the arrivals until the last arrival
+    // overwrites it — and are ranked afterwards.
+    bool has_long = false;
+    {
+        uint4 t[FJ_V], tn[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = k * FJ_BLOCK + tid;
+            t[k] = make_uint4(0, 0, 0, 0);
+            if (i < bc) { if (RES) t[k] = ltup[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; t[k].x = kv.x; t[k].y = kv.y; } }
+        }
+        for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + tid;
+                tn[k] = make_uint4(0, 0, 0, 0);
+                if (i < bc) { if (RES) tn[k] = ltup[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; tn[k].x = kv.x; tn[k].y = kv.y; } }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = i0 + k * FJ_BLOCK + tid;
+                if (i < bc) {
+                    const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
+                    const uint32_t sl = X.slot(h);
+                    const uint32_t a = X.H(sl + 1u), n = X.H(sl + 2u) - a;
+                    uint32_t v = (fj_tag(h) << 16) | i;
+                    if (n <= FJ_LONG) {
+                        for (uint32_t p = a;; ++p) {
+                            const uint32_t old = atomicMax(&X.ent[p], v);
+                            if (old == 0) break;
+                            v = min(old, v);
+                        }
+                    } else {
+                        has_long = true;
+                        const uint32_t arrival = atomicAdd(&X.ent[a + n - 1u], 1u);
+                        X.ent[a + arrival] = v;      // arrival n - 1: everybody has counted, the counter cell is free
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) t[k] = tn[k];
+        }
+    }
+    if (dbgu && threadIdx.x == 0) dbgu[7] = __builtin_amdgcn_s_memrealtime();
+    if (__syncthreads_or(has_long)) {
+        // long slots: one at a time, ranked by the whole workgroup (descending value)
+        for (uint32_t next = 0;;) {
+            if (tid == 0) *sh_pick = 0xffffffffu;
+            __syncthreads();
+            for (uint32_t sl = tid; sl < X.hs; sl += FJ_BLOCK)
+                if (sl >= next && X.H(sl + 2u) - X.H(sl + 1u) > FJ_LONG) { atomicMin(sh_pick, sl); break; }
+            __syncthreads();
+            const uint32_t pick = *sh_pick;
+            if (pick == 0xffffffffu) break;
+            const uint32_t a = X.H(pick + 1u), n = X.H(pick + 2u) - a;
+            for (uint32_t i = tid; i < n; i += FJ_BLOCK) {
+                const uint32_t v = X.ent[a + i];
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < n; ++j) r += X.ent[a + j] > v;
+                tmp[r] = v;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += FJ_BLOCK) X.ent[a + i] = tmp[i];
+            next = pick + 1u;
+            __syncthreads();
+        }
+    }
 }
 
 // Count the matches of one batch (FJ_V probe tuples per lane): lockstep rounds of
@@ -1050,17 +1205,16 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather 
                                                uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
                                                const FjOvf &O)
 {
-    uint32_t cur[FJ_V], tg[FJ_V];
+    uint32_t sn[FJ_V], tm[FJ_V];
 #pragma unroll
     for (int k = 0; k < FJ_V; ++k) {
-        const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
-        tg[k] = t32_tag(h);
-        cur[k] = okk[k] ? X.head(X.slot(h)) : 0;
+        fj_lookup(X, ((uint64_t)q[k].y << 32) | q[k].x, okk[k], sn[k], tm[k]);
         c[k] = 0; flo[k] = 0; fhi[k] = 0; fp[k] = false;
     }
-    for (uint32_t round = 0;; ++round) {
+    bool last = false;
+    for (uint32_t round = 0; !last; ++round) {
         uint32_t pos[FJ_V];
-        if (!fj_walk_round(X, cur, tg, pos)) break;
+        if (!fj_round(X, sn, tm, pos, last)) break;
         uint4 g[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
@@ -1251,6 +1405,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
     __shared__ uint32_t sh_u;
     __shared__ uint32_t sh_ovf;
+    __shared__ uint32_t sh_pick;
     __shared__ uint64_t sh_base;
     __shared__ uint32_t wsum[FJ_WAVES];
     const JoinArgs &a = f.j;
@@ -1279,22 +1434,22 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     const rhj_tuple *pr = (flip ? a.partS : a.partR) + ppos;
     const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
     const uint32_t bc = (uint32_t)(flip ? cR : cS);
-    // LDS: [resident build tuples 16 B x bc] [node 4 B x bc] [head links 2 B x hs]
+    // LDS: [resident build tuples 16 B x bc] [entries 4 B x (bc + 8)] [slot starts 2 B x (hs + 1)]
     const uint32_t bcp = (bc + 3u) & ~3u;
-    // head slots: one per build tuple when that fits behind the nodes, fewer (longer chains) for the
+    // slots: one per build tuple when that fits behind the entries, fewer (longer slots) for the
     // largest build sides, never below a quarter (host-side cap: 4.5 B per build tuple)
     uint32_t hs0 = bc < 64u ? 64u : bc;
     {
-        const uint32_t room = (lds_bytes - 16u - 4u * bcp) / 2u;      // 16-bit links that still fit
+        const uint32_t room = (lds_bytes - 64u - 4u * bcp) / 2u - 2u; // 16-bit slot starts that still fit
         if (hs0 > room) hs0 = room & ~1u;
     }
     // build tuples go to LDS too when they fit beside the index (wave-uniform per unit)
-    const bool RES = MAYRES && f.allow_resident && (size_t)bcp * 20 + (size_t)(hs0 + 1) / 2 * 4 + 16 <= lds_bytes;
+    const bool RES = MAYRES && f.allow_resident && (size_t)bcp * 20 + (size_t)(hs0 + 3) / 2 * 4 + 64 <= lds_bytes;
     uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
     FjIndex X;
-    X.node = tbl + (RES ? 4u * bcp : 0u);
+    X.ent = tbl + (RES ? 4u * bcp : 0u);
     X.hs = hs0;
-    X.headw = X.node + bcp;
+    X.dirw = X.ent + bcp + 8u;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
     uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
@@ -1309,36 +1464,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
-    for (uint32_t sidx = threadIdx.x; sidx < (X.hs + 1u) / 2u; sidx += FJ_BLOCK) X.headw[sidx] = 0;
-    __syncthreads();
-    {
-        uint4 t[FJ_V], tn[FJ_V];                       // current and prefetched batch of build tuples
-#pragma unroll
-        for (int k = 0; k < FJ_V; ++k) {
-            const uint32_t i = k * FJ_BLOCK + threadIdx.x;
-            t[k] = make_uint4(0, 0, 0, 0);
-            if (i < bc) { if (RES) t[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; t[k].x = kv.x; t[k].y = kv.y; } }
-        }
-        for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
-#pragma unroll
-            for (int k = 0; k < FJ_V; ++k) {               // next batch's loads fly while this batch is inserted
-                const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + threadIdx.x;
-                tn[k] = make_uint4(0, 0, 0, 0);
-                if (i < bc) { if (RES) tn[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; tn[k].x = kv.x; tn[k].y = kv.y; } }
-            }
-#pragma unroll
-            for (int k = 0; k < FJ_V; ++k) {
-                const uint32_t i = i0 + k * FJ_BLOCK + threadIdx.x;
-                if (i < bc) {
-                    if (RES) ltup[i] = t[k];
-                    fj_insert(X, ((uint64_t)t[k].y << 32) | t[k].x, i);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < FJ_V; ++k) t[k] = tn[k];
-        }
-    }
-    __syncthreads();
+    if (RES) fj_build<true>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick, f.dbg ? f.dbg + (size_t)u * 8 : nullptr);
+    else     fj_build<false>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick, f.dbg ? f.dbg + (size_t)u * 8 : nullptr);
     if (a.ablate == 1) continue;                      // timing experiment: build only
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
@@ -1412,7 +1539,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         pend = 0xffffffffu;
         __syncthreads();
     }
-    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 6] = (unit_needs_index ? 1u : 0u) | (RES ? 2u : 0u) | (emitting ? 4u : 0u) | ((uint64_t)total << 8);
+    if (false && f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 6] = (unit_needs_index ? 1u : 0u) | (RES ? 2u : 0u) | (emitting ? 4u : 0u) | ((uint64_t)total << 8);
     if (emitting && !RES && !unit_needs_index) {      // this unit's emit pass needs no index: defer it
         pend = u;
         pend_total = total;
@@ -1475,12 +1602,11 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 for (int k = 0; k < FJ_V; ++k) {
                     if (c[h][k] == 127u) {
                         const uint64_t hh = mix64(((uint64_t)q[h][k].y << 32) | q[h][k].x);
-                        const uint32_t t = t32_tag(hh);
-                        uint32_t n = 0, at = X.head(X.slot(hh));
-                        while (at != 0) {
-                            const uint32_t nd = X.node[at - 1u];
-                            if ((nd >> 16) == t) { const uint4 v = G.load(at - 1u); n += (v.x == q[h][k].x && v.y == q[h][k].y); }
-                            at = nd & 0xffffu;
+                        const uint32_t t = fj_tag(hh), sl = X.slot(hh);
+                        uint32_t n = 0;
+                        for (uint32_t at = X.H(sl + 1u), end = X.H(sl + 2u); at < end; ++at) {
+                            const uint32_t nd = X.ent[at];
+                            if ((nd >> 16) == t) { const uint4 v = G.load(nd & 0xffffu); n += (v.x == q[h][k].x && v.y == q[h][k].y); }
                         }
                         c[h][k] = n;
                     }
@@ -1517,22 +1643,21 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 #pragma unroll
         for (int h = 0; h < FJ_H; ++h) {
             uint64_t at[FJ_V];
-            uint32_t cur[FJ_V], tg[FJ_V];
+            uint32_t sn[FJ_V], tm[FJ_V];
             bool skip[FJ_V];
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
                 at[k] = wbase + off[h][k];
                 const bool direct = c[h][k] >= 1 && !fpt[h][k];             // stash holds its first emitted pair
                 if (direct) { if (at[k] < cap) out[at[k]] = make_pair(flip, q[h][k].z, q[h][k].w, flo[h][k], fhi[h][k]); ++at[k]; }
-                const uint64_t hh = mix64(((uint64_t)q[h][k].y << 32) | q[h][k].x);
-                tg[k] = t32_tag(hh);
                 const bool walk = direct ? c[h][k] >= 2 : c[h][k] >= 1;
-                cur[k] = walk ? X.head(X.slot(hh)) : 0;
+                fj_lookup(X, ((uint64_t)q[h][k].y << 32) | q[h][k].x, walk, sn[k], tm[k]);
                 skip[k] = direct;
             }
-            for (bool first_round = true;; first_round = false) {
+            bool last = false;
+            for (bool first_round = true; !last; first_round = false) {
                 uint32_t pos[FJ_V];
-                if (!fj_walk_round(X, cur, tg, pos)) break;
+                if (!fj_round(X, sn, tm, pos, last)) break;
                 if (first_round) {
 #pragma unroll
                     for (int k = 0; k < FJ_V; ++k)
@@ -1556,7 +1681,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         FJ_STAMP(dt_walk)
     }
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-    if (f.dbg && threadIdx.x == 64) { f.dbg[(size_t)u * 8 + 7] = ((uint64_t)dt_load << 32) | dt_scan; f.dbg[(size_t)u * 8 + 5] = dt_walk; }
+    if (false && f.dbg && threadIdx.x == 64) { f.dbg[(size_t)u * 8 + 7] = ((uint64_t)dt_load << 32) | dt_scan; f.dbg[(size_t)u * 8 + 5] = dt_walk; }
     }   // ticket loop
 
     if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup

@@ -1,0 +1,28 @@
+import importlib, ctypes as C, torch, sys, os
+import numpy as np
+sys.path.insert(0, ".")
+import bench
+os.environ["RHJ_STAMPS"] = "1"
+mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
+nR, nS = [int(x) for x in sys.argv[1:3]]
+w = dict(nR=nR, nS=nS, bits=12, dist="uniform")
+rhj.set_bits(12)
+R, S = bench.make_relations(w, rhj.dev, 1234)
+cap = max(nR, nS)
+out = torch.empty((cap, 2), dtype=torch.int64, device=rhj.dev)
+m = C.c_uint64(0)
+for i in range(3):
+    rhj.lib.rhj_join_device(R.data_ptr(), nR, S.data_ptr(), nS, out.data_ptr(), cap, C.byref(m))
+st = rhj.stats()
+units = st["units"]
+buf = np.zeros((units, 8), dtype=np.uint64)
+rhj.lib.rhj_debug_stamps.argtypes = [C.c_void_p, C.c_uint64]
+assert rhj.lib.rhj_debug_stamps(buf.ctypes.data_as(C.c_void_p), units) == 0
+t = buf.astype(np.int64)
+t0 = t[:, 0].min()
+us = lambda a: a / 100.0
+
+print("fused %.3f ms, units %d" % (st["ms_probe"], units))
+for name, a, b in (("count", 0, 5), ("scan", 5, 6), ("scatter", 6, 7), ("sort", 7, 1), ("build", 0, 1), ("phase1", 1, 2)):
+    d = us(t[:, b] - t[:, a])
+    print("%-10s mean %.1f p50 %.1f p90 %.1f" % (name, d.mean(), np.median(d), np.percentile(d, 90)))
