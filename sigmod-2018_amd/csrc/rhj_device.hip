@@ -72,7 +72,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_out[2] = {nullptr, nullptr};   // D2H staging of result pairs
@@ -131,6 +131,8 @@ int ctx_init()
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     g.ready = true;
     return 0;
 }
@@ -151,6 +153,12 @@ size_t scatter_lds_bytes(int bits)
 {
     const size_t bins = (size_t)1 << bits;
     return (size_t)PT_TILE * 16 + (PT_WAVES + 2) * bins * 4 + (PT_BLOCK / 64 + 1) * 8 + 16;
+}
+
+size_t scatter_runs_lds_bytes(int bits)
+{
+    const size_t bins = (size_t)1 << bits;
+    return (size_t)PT_TILE * 16 + (PT_WAVES + 3) * bins * 4 + (PT_BLOCK / 64 + 2) * 8 + (2 * PT_MAX_GROUP + 1) * 4 + 16;
 }
 
 // one stable pass over both relations: per-tile histogram, scan, LDS-staged scatter
@@ -194,7 +202,7 @@ int run_partition(PartState &ps, int bits, int nrel)
     if (ensure(g.histpsum, (size_t)4 * bins * 8) || ensure(g.passhp, (size_t)4 * 256 * 8)) return -1;
     ps.hist = (uint64_t *)g.histpsum.p;
     ps.psum = ps.hist + 2 * bins;
-    RelArgs none = RelArgs{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+    RelArgs none = RelArgs{};
     for (int i = 0; i < nrel; ++i) ps.r[i].tiles = tiles_for(ps.r[i].n);
     if (ensure(g.cntR, (size_t)ps.r[0].tiles * 256 * 4)) return -1;
     ps.r[0].cnt = (uint32_t *)g.cntR.p;
@@ -205,24 +213,72 @@ int run_partition(PartState &ps, int bits, int nrel)
     if (bits <= PT_MAX_BITS)
         return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, 0, bits, 0, ps.hist, ps.psum, true);
 
+    // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
     const int lo = bits / 2, hi = bits - lo;
+    const uint32_t bins1 = 1u << lo, bins2 = 1u << hi;
     uint64_t *ph = (uint64_t *)g.passhp.p, *pp = ph + 2 * 256;
     if (ensure(g.fullhist, (size_t)2 * bins * 4)) return -1;
-    HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
     RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
-    RelArgs b0 = a0, b1 = a1;
-    // pass 1 also writes every output tuple's pass-2 digit (1 B), so the pass-2 histogram reads n
-    // bytes instead of the 16n-byte tuples
-    if (ensure(g.digR, ps.r[0].n + 64)) return -1;
-    a0.out = ps.tmp[0]; b0.in = ps.tmp[0];
-    a0.dig_out = (uint8_t *)g.digR.p; b0.dig_in = (const uint8_t *)g.digR.p;
-    if (nrel > 1) {
-        if (ensure(g.digS, ps.r[1].n + 64)) return -1;
-        a1.out = ps.tmp[1]; b1.in = ps.tmp[1];
-        a1.dig_out = (uint8_t *)g.digS.p; b1.dig_in = (const uint8_t *)g.digS.p;
+    Buf *digb[2] = {&g.digR, &g.digS}, *runb[2] = {&g.runR, &g.runS}, *cntb[2] = {&g.cntR, &g.cntS};
+    RelArgs *ar[2] = {&a0, &a1};
+    uint32_t group = 15u * bins1 / 16u;               // a pass-2 tile averages 15/16 of 4096 tuples on uniform keys
+    if (group < 1) group = 1;
+    if (group > PT_MAX_GROUP - 1) group = PT_MAX_GROUP - 1;
+    for (int i = 0; i < nrel; ++i) {
+        RelArgs &a = *ar[i];
+        a.tiles1 = a.tiles;
+        a.group = group;
+        a.groups = (a.tiles1 + group - 1) / group;
+        if (ensure(*digb[i], a.n + 64) || ensure(*runb[i], (size_t)a.tiles1 * (bins1 + 1) * 2 + 64) ||
+            ensure(*cntb[i], (size_t)bins1 * a.groups * bins2 * 4))
+            return -1;
+        a.out = ps.tmp[i];
+        a.dig_out = (uint8_t *)digb[i]->p;
+        a.runs = (uint16_t *)runb[i]->p;
+        a.cnt = (uint32_t *)cntb[i]->p;
     }
-    if (partition_pass(a0, a1, nrel, 0, lo, bits, ph, pp, true, lo, hi)) return -1;
-    if (partition_pass(b0, b1, nrel, lo, hi, 0, ph, pp, false)) return -1;
+    RelArgs b0 = a0, b1 = a1;
+    RelArgs *br[2] = {&b0, &b1};
+    uint32_t max1 = 0, max2 = 0;
+    for (int i = 0; i < nrel; ++i) {
+        RelArgs &b = *br[i];
+        b.in = ps.tmp[i];
+        b.out = ps.r[i].out;
+        b.dig_in = (const uint8_t *)digb[i]->p;
+        b.dig_out = nullptr;
+        b.tiles = bins1 * b.groups;                   // pass-2 tiles
+        if (ar[i]->tiles > max1) max1 = ar[i]->tiles;
+        if (b.tiles > max2) max2 = b.tiles;
+    }
+    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_LAUNCH(k_local_part, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi);
+    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    {
+        const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
+        RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, nrel), dim3(HR_BLOCK), (size_t)bins2 * 4 * (HR_BLOCK / WAVE), g.stream,
+                   b0, b1, hi);
+    }
+    RHJ_LAUNCH(k_full_from_cnt, dim3(bins1, nrel), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
+    {
+        uint32_t chunks = (max2 + 15) / 16;
+        if (chunks > 512) chunks = 512;
+        if (chunks < 1) chunks = 1;
+        if (ensure(g.chunk, (size_t)2 * chunks * bins2 * 8)) return -1;
+        RHJ_LAUNCH(k_scan_chunks, dim3((bins2 + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, b0, b1, hi, chunks,
+                   (uint64_t *)g.chunk.p);
+        RHJ_LAUNCH(k_scan_bins, dim3(bins2, nrel), dim3(WAVE), 0, g.stream, hi, chunks, (uint64_t *)g.chunk.p, ph);
+        RHJ_LAUNCH(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, hi, (const uint64_t *)ph, pp);
+        RHJ_LAUNCH(k_scan_apply, dim3((bins2 + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, b0, b1, hi, chunks,
+                   (const uint64_t *)g.chunk.p, (const uint64_t *)pp);
+    }
+    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search
+    while (search0 * 2 <= group) search0 *= 2;
+    {
+        const uint32_t sgrid = (uint32_t)g.cus * 2u * 2u;     // two workgroups per CU resident, two tiles each and more
+        RHJ_LAUNCH(k_scatter_runs, dim3(max2 < sgrid ? max2 : sgrid, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+                   lo, hi, search0);
+    }
     RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
                        ps.psum);
     HIP_TRY(hipGetLastError());
@@ -611,7 +667,7 @@ void rhj_release(void)
     if (!g.ready) return;
     hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);

@@ -51,6 +51,13 @@ struct RelArgs {                 // one relation through one partition pass
     uint32_t         pad;
     const uint8_t   *dig_in;     // pass 2: this pass' digit per input tuple, written by pass 1 (else null)
     uint8_t         *dig_out;    // pass 1 of a two-pass partition: next pass' digit per OUTPUT tuple (else null)
+    // two-pass partition (run form): pass 1 partitions every tile in place and leaves a run table;
+    // a pass-2 tile is `group` consecutive pass-1 tiles' runs of one pass-1 digit
+    uint16_t        *runs;       // [bins1 + 1][tiles1] start of each digit's run inside its pass-1 tile; row bins1 = the tile's count
+    uint32_t         tiles1;     // pass-1 tiles
+    uint32_t         group;      // pass-1 tiles per pass-2 tile
+    uint32_t         groups;     // pass-2 tiles per pass-1 digit = ceil(tiles1 / group); tiles = bins1 * groups in pass 2
+    uint32_t         pad2;
 };
 
 struct Unit {
@@ -157,6 +164,7 @@ constexpr int PT_V = 8;                           // tuples per thread
 constexpr int PT_TILE = PT_BLOCK * PT_V;          // 4096 tuples = 64 KiB staged in LDS
 constexpr int PT_WAVES = PT_BLOCK / WAVE;
 constexpr int PT_MAX_BITS = 8;                    // digit bits per pass
+constexpr uint32_t PT_MAX_GROUP = 256;            // pass-1 tiles per pass-2 tile (run form), at most
 
 // Per-tile digit histogram of one pass: cnt[tile][digit] for digit = (key >> shift) & mask.
 // full_bits > 0 additionally accumulates the histogram of the low full_bits bits of the
@@ -399,6 +407,306 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
             if (r.dig_out) r.dig_out[dst] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
         }
     }
+}
+
+// ---- two-pass partition in run form (radix bits 9..15) ------------------------------------------
+// Pass 1 needs no histogram and no global offsets: every 4096-tuple tile is stably partitioned on
+// the LOW digit inside LDS and written back to the same place in the intermediate array, fully
+// coalesced, together with its run table (where each digit's run starts inside the tile) and each
+// tuple's HIGH digit as one byte.  The LSD order pass 2 must read — (low digit, tile, position) — is
+// then a sequence of runs: pass-2 tile (d, j) is the concatenation of the runs of digit d of pass-1
+// tiles [j * group, (j + 1) * group) — about 15/16 of 4096 tuples on uniform keys, any size on
+// skewed ones (processed 4096 at a time).  Histogram (from the digit bytes), scan and an LDS-staged
+// scatter over these tiles give the final array.  Compared with two offset-driven passes this drops
+// the first pass' histogram read of both relations and turns the first pass' scattered run writes
+// into streaming writes; pass 2 reads 1 KiB runs instead of a contiguous tile.
+__global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(dstart + 2 * bins);            // scan scratch
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= r.tiles) return;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint64_t beg = (uint64_t)tile * PT_TILE;
+    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+
+    for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+
+    uint4 t[PT_V];
+    bool ok[PT_V];
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
+        ok[k] = i < count;
+        if (ok[k]) t[k] = in[i];
+    }
+    __syncthreads();
+
+    uint32_t lrank[PT_V], dig[PT_V];
+    uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
+        const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
+        dig[k] = d;
+        uint64_t peers = __ballot(ok[k]);
+        for (int b = 0; b < bits; ++b) {
+            const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        uint32_t old = 0;
+        if (ok[k] && rank == 0) {                       // lowest lane of each digit group
+            old = mycnt[d];
+            mycnt[d] = old + (uint32_t)__popcll(peers);
+        }
+        const int leader = ok[k] ? __ffsll((unsigned long long)peers) - 1 : 0;
+        old = __shfl(old, leader, 64);
+        lrank[k] = old + rank;
+    }
+    __syncthreads();
+
+    uint64_t mytotal = 0;
+    if (threadIdx.x < bins) {
+        uint32_t run = 0;
+        for (int ww = 0; ww < PT_WAVES; ++ww) {
+            const uint32_t c = wcnt[ww * bins + threadIdx.x];
+            wcnt[ww * bins + threadIdx.x] = run;
+            run += c;
+        }
+        mytotal = run;
+    }
+    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+    if (threadIdx.x < bins) dstart[threadIdx.x] = (uint32_t)ds;
+    if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : count);
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k)
+        if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
+    __syncthreads();
+
+    uint4 *out = reinterpret_cast<uint4 *>(r.out) + beg;
+    uint8_t *dg = r.dig_out + beg;
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t p = k * PT_BLOCK + threadIdx.x;
+        if (p < count) {
+            const uint4 v = stage[p];
+            out[p] = v;
+            dg[p] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
+        }
+    }
+}
+
+// pass-2 tile -> its runs: thread i < group describes run i (two coalesced reads of the transposed table)
+__device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint32_t i, uint32_t &phys, uint32_t &len)
+{
+    const uint32_t d = tile2 / r.groups, j = tile2 % r.groups;
+    const uint32_t t = j * r.group + i;
+    phys = 0; len = 0;
+    if (i < r.group && t < r.tiles1) {
+        const uint32_t a = r.runs[(size_t)d * r.tiles1 + t], b = r.runs[(size_t)(d + 1) * r.tiles1 + t];
+        len = b - a;
+        phys = t * (uint32_t)PT_TILE + a;
+    }
+}
+
+// cnt[tile2][digit] of pass 2 from the digit bytes pass 1 wrote.  One WAVE per pass-2 tile, no
+// workgroup barrier: the lanes hold the run table, every run is one 64-byte load of the whole wave,
+// sixteen runs' loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
+// chain of dependent latencies: 6 us per tile, 0.32 ms for 100M + 100M tuples.)
+constexpr int HR_BLOCK = 256;
+__global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits)
+{
+    extern __shared__ uint32_t lds_u32[];
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t bins = 1u << bits;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *h = lds_u32 + w * bins;                 // this wave's histogram
+    const uint32_t stride = gridDim.x * (HR_BLOCK / WAVE);
+    for (uint32_t tile2 = blockIdx.x * (HR_BLOCK / WAVE) + w; tile2 < r.tiles; tile2 += stride) {
+        for (uint32_t b = lane; b < bins; b += WAVE) h[b] = 0;
+        for (uint32_t c0 = 0; c0 < r.group; c0 += WAVE) {
+            uint32_t phys, len;
+            pt_run_of(r, tile2, c0 + lane, phys, len);
+            const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
+            for (uint32_t q0 = 0; q0 < nrun; q0 += 16) {
+                uint32_t dg[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)phys, (int)((q0 + q) & 63u));
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)((q0 + q) & 63u));
+                    dg[q] = (q0 + q < nrun && lane < l) ? r.dig_in[p + lane] : 0xffffffffu;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (dg[q] != 0xffffffffu) atomicAdd(&h[dg[q]], 1u);
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)((q0 + q) & 63u));
+                    if (q0 + q < nrun && l > WAVE) {          // skewed keys: a run longer than one load
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)phys, (int)((q0 + q) & 63u));
+                        for (uint32_t e = lane + WAVE; e < l; e += WAVE) atomicAdd(&h[r.dig_in[p + e]], 1u);
+                    }
+                }
+            }
+        }
+        uint32_t *row = r.cnt + (size_t)tile2 * bins;
+        for (uint32_t b = lane; b < bins; b += WAVE) row[b] = h[b];
+    }
+}
+
+// bucket histogram of the full radix = column sums of pass 2's counts per pass-1 digit
+// (grid: pass-1 digits x relations; 1024 threads = digits x slices of the tile groups)
+__global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
+{
+    __shared__ uint32_t part[1024];
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t bins = 1u << bits, d = blockIdx.x;
+    const uint32_t b = threadIdx.x & (bins - 1u), slice = threadIdx.x >> bits, slices = 1024u >> bits;
+    uint32_t s = 0;
+    const uint32_t *base = r.cnt + (size_t)d * r.groups * bins + b;
+#pragma unroll 4
+    for (uint32_t j = slice; j < r.groups; j += slices) s += base[(size_t)j * bins];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < bins) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < slices; ++q) t += part[q * bins + threadIdx.x];
+        full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)] = t;
+    }
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint32_t *delta = dstart + bins;                                           // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(delta + bins);                 // scan scratch [PT_BLOCK / 64 + 1]
+    uint32_t *gbase = reinterpret_cast<uint32_t *>(sm + PT_BLOCK / 64 + 2);    // [bins] next output position per digit
+    uint32_t *runoff = gbase + bins;                                           // [PT_MAX_GROUP + 1] first element of run i
+    uint32_t *rbase = runoff + PT_MAX_GROUP + 1;                               // [PT_MAX_GROUP] physical index of element e of run i = rbase[i] + e
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in);
+    uint4 *out = reinterpret_cast<uint4 *>(r.out);
+
+    // workgroups walk the pass-2 tiles with a grid stride; the next tile's run table and output
+    // offsets are fetched while the current tile is moved
+    uint32_t nphys = 0, nlen = 0, ngb = 0;
+    if (blockIdx.x < r.tiles) {
+        pt_run_of(r, blockIdx.x, threadIdx.x, nphys, nlen);
+        if (threadIdx.x < bins) ngb = r.cnt[(size_t)blockIdx.x * bins + threadIdx.x];
+    }
+    for (uint32_t tile2 = blockIdx.x; tile2 < r.tiles; tile2 += gridDim.x) {
+    uint32_t total;
+    {
+        const uint32_t phys = nphys, len = nlen;
+        uint64_t tot64;
+        const uint32_t off = (uint32_t)block_excl_scan<PT_BLOCK>(len, &tot64, sm);
+        total = (uint32_t)tot64;
+        if (threadIdx.x < PT_MAX_GROUP) { runoff[threadIdx.x] = threadIdx.x < r.group ? off : total; rbase[threadIdx.x] = phys - off; }
+        if (threadIdx.x == 0) runoff[PT_MAX_GROUP] = total;
+        if (threadIdx.x < bins) gbase[threadIdx.x] = ngb;
+        const uint32_t nt = tile2 + gridDim.x;
+        nphys = 0; nlen = 0;
+        if (nt < r.tiles) {
+            pt_run_of(r, nt, threadIdx.x, nphys, nlen);
+            if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t sb = 0; sb < total; sb += PT_TILE) {
+        const uint32_t count = min((uint32_t)PT_TILE, total - sb);
+        for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+
+        uint4 t[PT_V];
+        bool ok[PT_V];
+#pragma unroll
+        for (int k = 0; k < PT_V; ++k) {
+            const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
+            ok[k] = i < count;
+            const uint32_t e = sb + i;
+            uint32_t pos = 0;                         // last run that starts at or before e
+            for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
+                if (runoff[pos + s2] <= e) pos += s2;
+            if (ok[k]) t[k] = in[rbase[pos] + e];
+        }
+        __syncthreads();
+
+        uint32_t lrank[PT_V], dig[PT_V];
+        uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+        for (int k = 0; k < PT_V; ++k) {
+            const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;
+            const uint32_t d = (uint32_t)(key >> shift) & mask;
+            dig[k] = d;
+            uint64_t peers = __ballot(ok[k]);
+            for (int b = 0; b < bits; ++b) {
+                const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            uint32_t old = 0;
+            if (ok[k] && rank == 0) {
+                old = mycnt[d];
+                mycnt[d] = old + (uint32_t)__popcll(peers);
+            }
+            const int leader = ok[k] ? __ffsll((unsigned long long)peers) - 1 : 0;
+            old = __shfl(old, leader, 64);
+            lrank[k] = old + rank;
+        }
+        __syncthreads();
+
+        uint64_t mytotal = 0;
+        if (threadIdx.x < bins) {
+            uint32_t run = 0;
+            for (int ww = 0; ww < PT_WAVES; ++ww) {
+                const uint32_t c = wcnt[ww * bins + threadIdx.x];
+                wcnt[ww * bins + threadIdx.x] = run;
+                run += c;
+            }
+            mytotal = run;
+        }
+        const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+        if (threadIdx.x < bins) {
+            dstart[threadIdx.x] = (uint32_t)ds;
+            const uint32_t gb = gbase[threadIdx.x];
+            delta[threadIdx.x] = gb - (uint32_t)ds;                 // mod 2^32
+            gbase[threadIdx.x] = gb + (uint32_t)mytotal;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int k = 0; k < PT_V; ++k)
+            if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
+        __syncthreads();
+
+#pragma unroll
+        for (int k = 0; k < PT_V; ++k) {
+            const uint32_t p = k * PT_BLOCK + threadIdx.x;
+            if (p < count) {
+                const uint4 v = stage[p];
+                const uint32_t d = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> shift) & mask;
+                out[delta[d] + p] = v;
+            }
+        }
+        __syncthreads();
+    }
+    }   // grid-stride loop
 }
 
 // ----------------------------------------------------------------------- plan
