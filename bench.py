@@ -243,6 +243,21 @@ def main():
         def gbs(b, ms):
             return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
+        part_ms = stage["ms_hist"] + stage["ms_scan"] + stage["ms_scatter"]
+        if w["bits"] <= 8:        # one pass: per-tile histogram, scan, LDS-staged scatter
+            part_bytes = hist_bytes + scatter_bytes
+            part = {"ms": part_ms, "GBps": gbs(part_bytes, part_ms), "algorithmic_bytes": part_bytes,
+                    "formula": "16*n read (histogram) + 16*n read + 16*n written (scatter), both relations",
+                    "histogram": {"ms": stage["ms_hist"], "GBps": gbs(hist_bytes, stage["ms_hist"])},
+                    "scan": {"ms": stage["ms_scan"]},
+                    "scatter": {"ms": stage["ms_scatter"], "GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
+        else:                     # two passes in run form (k_local_part, k_hist_runs + scan, k_scatter_runs)
+            part_bytes = 2 * scatter_bytes
+            part = {"ms": part_ms, "GBps": gbs(part_bytes, part_ms), "algorithmic_bytes": part_bytes,
+                    "formula": "2 passes x (16*n read + 16*n written), both relations",
+                    "pass1_tile_local": {"ms": stage["ms_hist"], "GBps": gbs(scatter_bytes, stage["ms_hist"])},
+                    "pass2_histogram_scan": {"ms": stage["ms_scan"]},
+                    "pass2_scatter_runs": {"ms": stage["ms_scatter"], "GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
         fused = stage["ms_count"] == 0.0 and stage["ms_probe"] > 0
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
         probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
@@ -267,14 +282,7 @@ def main():
                 "probe_tuples_per_s_e9": nS / (stage["ms_probe"] * 1e-3) / 1e9 if stage["ms_probe"] > 0 else 0.0,
                 "join_phase_ms": join_ms,
                 "join_phase_GBps": gbs(probe_bytes, join_ms),
-                "partition": {"ms": stage["ms_hist"] + stage["ms_scan"] + stage["ms_scatter"],
-                              "GBps": gbs(hist_bytes + scatter_bytes, stage["ms_hist"] + stage["ms_scan"] + stage["ms_scatter"]),
-                              "algorithmic_bytes": hist_bytes + scatter_bytes,
-                              "formula": "16*n read (pass-1 histogram) + 16*n read + 16*n written (scatter), both relations"},
-                "hist_pass1": {"ms": stage["ms_hist"], "GBps": gbs(hist_bytes, stage["ms_hist"])},
-                "scan_pass1": {"ms": stage["ms_scan"]},
-                "scatter_all": {"ms": stage["ms_scatter"],
-                                "what": "scatter pass 1" + ("" if w["bits"] <= 8 else " + histogram, scan and scatter of pass 2")},
+                "partition": part,
                 "plan": {"ms": stage["ms_plan"]},
                 "build_tables": {"ms": stage["ms_build"]}, "count": {"ms": stage["ms_count"]},
                 "offsets": {"ms": stage["ms_offsets"]},

@@ -191,11 +191,14 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
     return 0;
 }
 
-// Stable radix partition of one or two relations on the low `bits` bits.  bits <= 8:
-// one pass.  bits 9..12: two LSD passes (low half into tmp, high half into out); the
-// bucket histogram of the full radix comes from the first pass' histogram kernel.
-// Stage events: ST_HIST..ST_SCAN first histogram, ST_SCAN..ST_SCATTER first scan,
-// ST_SCATTER..ST_PLAN everything else (scatter passes, second histogram + scan).
+// Stable radix partition of one or two relations on the low `bits` bits.  bits <= 8: one pass
+// (per-tile histogram, scan, LDS-staged scatter).  bits 9..15: two LSD passes in run form — pass 1
+// partitions every tile in place on the low half of the bits (no histogram, no offsets), pass 2
+// moves the runs to their final places on the high half; the bucket histogram of the full radix is
+// the column sum of pass 2's per-tile counts.
+// Stage events: one pass  ST_HIST..ST_SCAN histogram, ST_SCAN..ST_SCATTER scan, ST_SCATTER..ST_PLAN scatter;
+//               two passes ST_HIST..ST_SCAN pass 1, ST_SCAN..ST_SCATTER pass-2 histogram + scan,
+//                          ST_SCATTER..ST_PLAN pass-2 scatter.
 int run_partition(PartState &ps, int bits, int nrel)
 {
     const uint32_t bins = 1u << bits;
@@ -275,8 +278,9 @@ int run_partition(PartState &ps, int bits, int nrel)
     uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search
     while (search0 * 2 <= group) search0 *= 2;
     {
-        const uint32_t sgrid = (uint32_t)g.cus * 2u * 2u;     // two workgroups per CU resident, two tiles each and more
-        RHJ_LAUNCH(k_scatter_runs, dim3(max2 < sgrid ? max2 : sgrid, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+        const uint32_t sgrid = (uint32_t)g.cus * 2u;          // the workgroups that are resident together (two per CU)
+        const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;     // a multiple of the 8 XCDs
+        RHJ_LAUNCH(k_scatter_runs, dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
                    lo, hi, search0);
     }
     RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,

@@ -603,14 +603,22 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
     const uint4 *in = reinterpret_cast<const uint4 *>(r.in);
     uint4 *out = reinterpret_cast<uint4 *>(r.out);
 
-    // workgroups walk the pass-2 tiles with a grid stride; the next tile's run table and output
-    // offsets are fetched while the current tile is moved
+    // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx.x % 8), each with its own L2.
+    // Consecutive pass-2 tiles write ADJACENT pieces of every digit's output, so the cache line at the
+    // seam is completed by the neighbour tile: an XCD takes a contiguous eighth of the tiles and its
+    // workgroups walk it together, so both halves of a seam line meet in the same L2 and leave as one
+    // full-line write.  The next tile's run table and output offsets are fetched while the current
+    // tile is moved.
+    const uint32_t xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;           // gridDim.x is a multiple of 8
+    const uint32_t share = (r.tiles + 7u) / 8u;
+    const uint32_t t_end = min(r.tiles, (xcd + 1u) * share);
+    const uint32_t t_first = xcd * share + (blockIdx.x >> 3);
     uint32_t nphys = 0, nlen = 0, ngb = 0;
-    if (blockIdx.x < r.tiles) {
-        pt_run_of(r, blockIdx.x, threadIdx.x, nphys, nlen);
-        if (threadIdx.x < bins) ngb = r.cnt[(size_t)blockIdx.x * bins + threadIdx.x];
+    if (t_first < t_end) {
+        pt_run_of(r, t_first, threadIdx.x, nphys, nlen);
+        if (threadIdx.x < bins) ngb = r.cnt[(size_t)t_first * bins + threadIdx.x];
     }
-    for (uint32_t tile2 = blockIdx.x; tile2 < r.tiles; tile2 += gridDim.x) {
+    for (uint32_t tile2 = t_first; tile2 < t_end; tile2 += per_xcd) {
     uint32_t total;
     {
         const uint32_t phys = nphys, len = nlen;
@@ -620,9 +628,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
         if (threadIdx.x < PT_MAX_GROUP) { runoff[threadIdx.x] = threadIdx.x < r.group ? off : total; rbase[threadIdx.x] = phys - off; }
         if (threadIdx.x == 0) runoff[PT_MAX_GROUP] = total;
         if (threadIdx.x < bins) gbase[threadIdx.x] = ngb;
-        const uint32_t nt = tile2 + gridDim.x;
+        const uint32_t nt = tile2 + per_xcd;
         nphys = 0; nlen = 0;
-        if (nt < r.tiles) {
+        if (nt < t_end) {
             pt_run_of(r, nt, threadIdx.x, nphys, nlen);
             if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
         }
