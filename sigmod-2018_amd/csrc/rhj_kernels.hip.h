@@ -643,14 +643,25 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
 
         uint4 t[PT_V];
         bool ok[PT_V];
+        uint32_t pos = 0;                             // last run that starts at or before the element
 #pragma unroll
         for (int k = 0; k < PT_V; ++k) {
             const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
             ok[k] = i < count;
             const uint32_t e = sb + i;
-            uint32_t pos = 0;                         // last run that starts at or before e
-            for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
-                if (runoff[pos + s2] <= e) pos += s2;
+            if (k == 0) {
+                for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
+                    if (runoff[pos + s2] <= e) pos += s2;
+            } else {
+                // 64 elements further on: usually the next run or the one after it
+                if (runoff[pos + 1] <= e) ++pos;
+                if (runoff[pos + 1] <= e) ++pos;
+                if (runoff[pos + 1] <= e) {           // short or empty runs in between: search again
+                    pos = 0;
+                    for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
+                        if (runoff[pos + s2] <= e) pos += s2;
+                }
+            }
             if (ok[k]) t[k] = in[rbase[pos] + e];
         }
         __syncthreads();
