@@ -262,6 +262,22 @@ def main():
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
         probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
                         else "k_probe<WRITE> (emit pass of the tiled path)")
+        # HBM-side bytes of the dominant kernel per launch: rocprofv3 --pmc passes of this same command,
+        # committed under profiles/ (tools/pmc.sh; counters cannot be read from inside this process)
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_%s_pmc.json" % args.workload)))
+            if cands and fused:
+                pm = json.load(open(cands[-1]))
+                for kname, kv in pm.items():
+                    if "k_join_fused" in kname and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
+                        traffic = int((kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024)
+                        traffic_src = ("%s: FETCH_SIZE + WRITE_SIZE of the last dispatch, uncorrected (8 B/lane key streams and "
+                                       "16 B divergent gathers are not the calibrated 16 B/lane streaming case of the guide)"
+                                       % os.path.basename(cands[-1]))
+        except Exception:
+            traffic, traffic_src = None, None
         res = {
             "metric": "probe throughput (10^9 tuples/s) + achieved HBM GB/s",
             "value": world * nS * args.steps / elapsed / 1e9,
@@ -275,7 +291,7 @@ def main():
                        "path": "fused" if fused else "tiled", "units": st["units"], "max_build_side": st["max_build"]},
             "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"],
                          "formula": "16*nS + 16*nR + 16*matches (SURVEY.md 8d)"},
             "kernels": {
