@@ -29,6 +29,14 @@ ABI_SYMBOLS = [
     "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_join_device", "rhj_partition_device", "rhj_filter_device",
     "rhj_register_relation_map", "rhj_release", "rhj_last_stats", "rhj_version",
 ]
+# every symbol include/rhj_inter.h declares (device-resident intermediate results)
+INTER_SYMBOLS = [
+    "InitInterData", "FreeInterData", "InitInterResults", "PrintInterResults", "FreeInterResults",
+    "InsertJoinToInterResults", "GetRelation", "ScanInterResults", "SelfJoin", "MergeInterNodes", "Merge",
+    "CalculateQueryResults", "PrintNullResults", "AreActiveInInter", "JoinInterNode", "CartesianInterResults",
+    "InsertSingleRowIdsToInterResult", "rhj_gather_tables_device", "rhj_build_relation_device", "rhj_sum_gather_device",
+    "rhj_filter_eq2_device", "rhj_resident_relation", "rhj_resident_result", "rhj_resident_inter",
+]
 
 
 class Relation(C.Structure):

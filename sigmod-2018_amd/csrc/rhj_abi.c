@@ -64,6 +64,12 @@ rhj_result *RadixHashJoin(rhj_relation *relR, rhj_relation *relS, struct schedul
 {
     (void)sched;                                     /* may be NULL (handler.c:60-63) */
     if (relR->num_tuples == 0 || relS->num_tuples == 0) return NULL;   /* rhjoin.c:15-16 */
+    /* relations materialised by this library's GetRelation() live on the device (rhj_inter.h):
+     * the match list then stays there too */
+    if (rhj_resident_relation(relR) || rhj_resident_relation(relS)) {
+        if (!(rhj_resident_relation(relR) && rhj_resident_relation(relS))) fatal("RadixHashJoin (one device-resident, one host relation)");
+        return rhj_resident_join(relR, relS);
+    }
     list_sink sink = {NULL, NULL, sizeof(rhj_result_tuple), 0};
     uint64_t matches = 0;
     int rc = rhj_host_join(relR->tuples, relR->num_tuples, relS->tuples, relS->num_tuples, &matches,
@@ -83,6 +89,7 @@ rhj_result *RadixHashJoin(rhj_relation *relR, rhj_relation *relS, struct schedul
 
 rhj_result *Filter(rhj_inter_res *head, rhj_filter_pred *filter_p, rhj_relation_map *map, int *query_relations)
 {
+    if (rhj_resident_inter(head)) return rhj_resident_filter(head, filter_p, map, query_relations);   /* rhj_inter.h */
     const uint64_t relation = (uint64_t)filter_p->relation, column = (uint64_t)filter_p->column;
     const rhj_relation_map *rm = &map[query_relations[relation]];
     const uint64_t *col = rm->columns[column];                         /* filter.c:96 */
@@ -155,8 +162,14 @@ uint64_t FindResultRowId(rhj_result *res, int num)
 {
     uint64_t count = 0;
     for (; res; res = res->next) {
-        if (res->current_load + count > (uint64_t)num)
+        if (res->current_load + count > (uint64_t)num) {
+            if (rhj_resident_result(res)) {
+                uint64_t v = 0;
+                if (rhj_resident_fetch(res, sizeof(uint64_t), (uint64_t)num - count, &v)) fatal("FindResultRowId");
+                return v;
+            }
             return ((uint64_t *)res->buff)[(uint64_t)num - count];
+        }
         count += res->current_load;
     }
     return 0;
@@ -167,8 +180,14 @@ rhj_result_tuple *FindResultTuples(rhj_result *head, int num)
     uint64_t count = 0;
     if (num < 0) return NULL;
     for (; head; head = head->next) {
-        if (head->current_load + count > (uint64_t)num)
+        if (head->current_load + count > (uint64_t)num) {
+            if (rhj_resident_result(head)) {            /* a copy of the element: the list itself is on the device */
+                static rhj_result_tuple copy;
+                if (rhj_resident_fetch(head, sizeof(rhj_result_tuple), (uint64_t)num - count, &copy)) fatal("FindResultTuples");
+                return &copy;
+            }
             return (rhj_result_tuple *)head->buff + ((uint64_t)num - count);
+        }
         count += head->current_load;
     }
     return NULL;
@@ -176,6 +195,7 @@ rhj_result_tuple *FindResultTuples(rhj_result *head, int num)
 
 void FreeResult(rhj_result *head)
 {
+    if (rhj_resident_result(head)) { rhj_resident_free_result(head); return; }
     while (head) {
         rhj_result *t = head;
         head = head->next;
@@ -187,6 +207,10 @@ void FreeResult(rhj_result *head)
 void PrintResult(rhj_result *head)
 {
     uint64_t total = 0;
+    if (rhj_resident_result(head)) {
+        fprintf(stderr, "device-resident result list: %lu elements\n", (unsigned long)head->current_load);
+        return;
+    }
     fprintf(stderr, "------------------------------\nPrinting results:\n");
     for (; head; head = head->next) {
         const rhj_result_tuple *p = (const rhj_result_tuple *)head->buff;
@@ -200,6 +224,7 @@ void PrintResult(rhj_result *head)
 void FreeRelation(rhj_relation *rel)
 {
     if (rel == NULL) return;
+    if (rhj_resident_relation(rel)) { rhj_resident_free_relation(rel); return; }
     free(rel->tuples);
     free(rel);
 }

@@ -78,6 +78,8 @@ struct Ctx {
     void *pin_out[2] = {nullptr, nullptr};   // D2H staging of result pairs
     hipEvent_t ev_pin[2] = {};
     std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
+    std::multimap<size_t, void *> free_blocks;                  // rhj_dev_alloc: cached blocks by size
+    std::map<void *, size_t> live_blocks;                       // rhj_dev_alloc: blocks handed out
     rhj_stats stats = {};
 };
 
@@ -572,6 +574,34 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
     return 0;
 }
 
+int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t *colB, const uint64_t *selB, uint64_t n,
+                      uint64_t *d_out, uint64_t *hits)
+{
+    if (ctx_init()) return -1;
+    *hits = 0;
+    if (n == 0) return 0;
+    const uint64_t tiles = (n + FILTER_TILE - 1) / FILTER_TILE;
+    if (ensure(g.fmask, ((n + 63) / 64 + FILTER_ROUNDS * 8 + 8) * 8) || ensure(g.ftile, tiles * 8) ||
+        ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary)))
+        return -1;
+    uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
+    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_LAUNCH(k_filter_mask_eq2, dim3((unsigned)tiles), dim3(256), 0, g.stream, colA, selA, colB, selB, n,
+               (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
+    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
+    RHJ_LAUNCH(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
+                       (const uint64_t *)g.fbase.p, d_out);
+    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *hits = *(uint64_t *)g.pin;
+    memset(&g.stats, 0, sizeof(g.stats));
+    g.stats.n_r = n; g.stats.matches = *hits;
+    g.stats.ms_total = g.stats.ms_probe = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ C-ABI
@@ -676,6 +706,10 @@ void rhj_release(void)
     for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) hipFree(kv.second);
     g.columns.clear();
+    for (auto &kv : g.free_blocks) hipFree(kv.second);
+    g.free_blocks.clear();
+    for (auto &kv : g.live_blocks) hipFree(kv.first);
+    g.live_blocks.clear();
 }
 
 // ---- host-side staging used by rhj_abi.c (not part of the public header) ----
@@ -800,5 +834,68 @@ int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel,
 
 int rhj_host_null_on_empty(void) { return g.null_on_empty; }
 uint64_t rhj_host_node_pairs(void) { return g.node_pairs; }
+
+// ---- device-side services for rhj_inter.hip (device-resident intermediate results) ----
+
+// Device blocks of the intermediate results.  Everything that touches them is queued on the one
+// library stream, so a freed block can be handed out again at once: the new user's work is ordered
+// behind the old user's by the stream itself.  Blocks are cached by size (never returned to the
+// driver before rhj_release()), which keeps hipMalloc/hipFree — both device-wide synchronisations —
+// out of the per-operator path.  (hipMallocAsync/hipFreeAsync were tried first: on this stack a
+// block freed with work still queued came back with stale contents visible to later kernels.)
+void *rhj_dev_alloc(size_t bytes)
+{
+    if (ctx_init()) return nullptr;
+    size_t want = bytes < 256 ? 256 : bytes;
+    if (want <= ((size_t)1 << 20)) { size_t c = 256; while (c < want) c <<= 1; want = c; }      // power-of-two classes
+    else want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);                       // 1 MiB granules
+    auto it = g.free_blocks.lower_bound(want);
+    if (it != g.free_blocks.end() && it->first <= want + want / 4) {
+        void *p = it->second;
+        g.live_blocks[p] = it->first;
+        g.free_blocks.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        // out of device memory: give the cached blocks back and try once more
+        (void)hipStreamSynchronize(g.stream);
+        for (auto &kv : g.free_blocks) (void)hipFree(kv.second);
+        g.free_blocks.clear();
+        if (hipMalloc(&p, want) != hipSuccess) {
+            fprintf(stderr, "rhj: device allocation of %zu bytes failed\n", bytes);
+            return nullptr;
+        }
+    }
+    g.live_blocks[p] = want;
+    return p;
+}
+void rhj_dev_free(void *p)
+{
+    if (!p) return;
+    auto it = g.live_blocks.find(p);
+    if (it == g.live_blocks.end()) return;
+    g.free_blocks.emplace(it->second, p);
+    g.live_blocks.erase(it);
+}
+void *rhj_dev_stream(void) { return ctx_init() ? nullptr : (void *)g.stream; }
+const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows)
+{
+    if (ctx_init()) return nullptr;
+    return (const uint64_t *)column_device(host_col, rows);
+}
+int rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out, uint64_t *matches)
+{
+    *out = nullptr; *matches = 0;
+    return join_device(d_R, nR, d_S, nS, nullptr, 0, true, out, matches);
+}
+int rhj_filter_eq2_device(const uint64_t *d_colA, const uint64_t *d_selA, const uint64_t *d_colB, const uint64_t *d_selB,
+                          uint64_t n, uint64_t *d_out, uint64_t *hits)
+{
+    uint64_t h = 0;
+    const int rc = filter_eq2_device(d_colA, d_selA, d_colB, d_selB, n, d_out, &h);
+    if (hits) *hits = h;
+    return rc;
+}
 
 }  // extern "C"

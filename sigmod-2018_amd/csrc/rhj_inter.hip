@@ -1,0 +1,613 @@
+// rhj_inter.hip — device-resident intermediate results (include/rhj_inter.h): the reference's
+// inter_res.c and the helper half of filter.c restated over row-id tables that live on the GPU.
+// Control flow (which node, which relation is active, what becomes NULL) follows the reference
+// function by function; every loop over tuples is one gather / scan / reduction kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_set>
+#include <vector>
+
+#include "rhj.h"
+#include "rhj_inter.h"
+#include "rhj_internal.h"
+
+namespace {
+
+constexpr int MAX_TABLES = 16;                      // relations per query the gather kernel takes in one launch
+
+struct GatherArgs {
+    uint64_t       *dst[MAX_TABLES];
+    const uint64_t *src[MAX_TABLES];                 // nullptr: write the index itself
+    int             ntab;
+};
+
+// dst[t][i] = src[t][idx[i * stride]]: the index is read once per row, every table is a coalesced
+// write and a random 8-byte read (inter_res.c:95-101,131-137,304-313; filter.c:73-77)
+__global__ __launch_bounds__(256) void k_gather_tables(GatherArgs a, const uint64_t *idx, int stride, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p = idx[i * (uint64_t)stride];
+#pragma unroll 4
+    for (int t = 0; t < a.ntab; ++t) a.dst[t][i] = a.src[t] ? a.src[t][p] : p;
+}
+
+// tuples[i] = {col[sel ? sel[i] : i], i}   (inter_res.c:199-204, :223-227)
+__global__ __launch_bounds__(256) void k_build_relation(const uint64_t *col, const uint64_t *sel, uint64_t n, rhj_tuple *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = col[sel ? sel[i] : i];
+    reinterpret_cast<ulonglong2 *>(out)[i] = make_ulonglong2(v, i);
+}
+
+// sum += col[sel[i]] with wrap-around (inter_res.c:329-333)
+__global__ __launch_bounds__(256) void k_sum_gather(const uint64_t *col, const uint64_t *sel, uint64_t n, unsigned long long *sum)
+{
+    __shared__ unsigned long long part[4];
+    unsigned long long s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        s += col[sel ? sel[i] : i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+
+// new[z][i * n2 + j] = a[z][i] if a[z] else b[z][j]   (inter_res.c:409-421)
+struct CartArgs {
+    uint64_t       *dst[MAX_TABLES];
+    const uint64_t *a[MAX_TABLES];
+    const uint64_t *b[MAX_TABLES];
+    int             ntab;
+};
+__global__ __launch_bounds__(256) void k_cartesian(CartArgs c, uint64_t n1, uint64_t n2)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n1 * n2) return;
+    const uint64_t i = x / n2, j = x % n2;
+    for (int t = 0; t < c.ntab; ++t) c.dst[t][x] = c.a[t] ? c.a[t][i] : c.b[t][j];
+}
+
+std::unordered_set<const void *> g_rel, g_res, g_inter;
+
+// RHJ_TRACE=1: one line per call on stderr (which operator, which relations, how many rows)
+bool tracing() { static const bool on = getenv("RHJ_TRACE") != nullptr; return on; }
+#define TRACE(...) do { if (tracing()) { fprintf(stderr, "rhj-trace: " __VA_ARGS__); fputc('\n', stderr); } } while (0)
+void trace_nodes(const rhj_inter_res *h)
+{
+    if (!tracing()) return;
+    for (int k = 0; h; h = h->next, ++k) {
+        fprintf(stderr, "rhj-trace:   node %d rows %lu active", k, (unsigned long)h->data->num_tuples);
+        for (int j = 0; j < h->num_of_relations; ++j) if (h->data->table[j]) fprintf(stderr, " %d", j);
+        fputc('\n', stderr);
+    }
+}
+
+hipStream_t stream() { return (hipStream_t)rhj_dev_stream(); }
+
+[[noreturn]] void die(const char *what)
+{
+    // same convention as the rest of the boundary: no error channel, print and exit(2)
+    fprintf(stderr, "rhj: %s failed on the device path; there is no CPU fallback\n", what);
+    exit(2);
+}
+
+void check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) { fprintf(stderr, "rhj: %s: %s\n", what, hipGetErrorString(e)); die(what); }
+}
+
+uint64_t *alloc_ids(uint64_t n)
+{
+    uint64_t *p = (uint64_t *)rhj_dev_alloc(n * 8);
+    if (!p) die("device allocation");
+    return p;
+}
+
+rhj_result *make_result(void *dbuff, uint64_t count)
+{
+    rhj_result *r = (rhj_result *)malloc(sizeof(rhj_result));
+    r->buff = (char *)dbuff;
+    r->next = nullptr;
+    r->current_load = count;
+    g_res.insert(r);
+    return r;
+}
+
+uint64_t result_count(const rhj_result *res)
+{
+    uint64_t n = 0;
+    for (; res; res = res->next) n += res->current_load;   // results.c:65-76 (there as int)
+    return n;
+}
+
+const uint64_t *result_ids(const rhj_result *res)
+{
+    if (res == nullptr) return nullptr;
+    if (!rhj_resident_result(res)) die("a host result list handed to the device-resident intermediate results");
+    return (const uint64_t *)res->buff;
+}
+
+void gather(uint64_t *const *dst, const uint64_t *const *src, int ntab, const uint64_t *idx, int stride, uint64_t n)
+{
+    if (rhj_gather_tables_device(dst, src, ntab, idx, stride, n)) die("gather");
+}
+
+const uint64_t *column_of(const rhj_relation_map *rm, int column)
+{
+    const uint64_t *d = rhj_dev_column(rm->columns[column], rm->num_tuples);
+    if (!d) die("staging a column on the device");
+    return d;
+}
+
+// the first node in which `rel` is active (inter_res.c:184-190, :243-249; filter.c:98-104)
+rhj_inter_res *node_of(rhj_inter_res *inter, int rel)
+{
+    while (inter && inter->data->table[rel] == nullptr) inter = inter->next;
+    return inter;
+}
+
+// Rebuild `node` with `count` rows: every active relation j gets new[j][i] = old[j][idx[i * stride]];
+// `fresh_rel` (or -1) becomes active with new[fresh_rel][i] = fresh_idx[i * stride].
+// inter_res.c:64-104 / :106-140 / filter.c:45-81.
+void rebuild_node(rhj_inter_res *node, uint64_t count, const uint64_t *idx, int stride, int fresh_rel, const uint64_t *fresh_idx)
+{
+    const int nrel = node->num_of_relations;
+    rhj_inter_data *nd = nullptr;
+    InitInterData(&nd, nrel, (int)count);
+    nd->num_tuples = count;
+    std::vector<uint64_t *> dst;
+    std::vector<const uint64_t *> src;
+    for (int j = 0; j < nrel; ++j) {
+        if (node->data->table[j] != nullptr && j != fresh_rel) {
+            nd->table[j] = alloc_ids(count);
+            dst.push_back(nd->table[j]);
+            src.push_back(node->data->table[j]);
+        }
+    }
+    for (size_t at = 0; at < dst.size(); at += MAX_TABLES)
+        gather(dst.data() + at, src.data() + at, (int)std::min<size_t>(MAX_TABLES, dst.size() - at), idx, stride, count);
+    if (fresh_rel >= 0) {
+        nd->table[fresh_rel] = alloc_ids(count);
+        uint64_t *d = nd->table[fresh_rel];
+        const uint64_t *s = nullptr;
+        gather(&d, &s, 1, fresh_idx, stride, count);
+    }
+    FreeInterData(node->data, nrel);
+    node->data = nd;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ identity of resident objects
+
+int rhj_resident_relation(const rhj_relation *rel) { return rel && g_rel.count(rel); }
+int rhj_resident_result(const rhj_result *res) { return res && g_res.count(res); }
+int rhj_resident_inter(const rhj_inter_res *head) { return head && g_inter.count(head); }
+
+// ------------------------------------------------------------------ device entry points
+
+int rhj_gather_tables_device(uint64_t *const *dst, const uint64_t *const *src, int ntab, const uint64_t *idx,
+                             int idx_stride, uint64_t n)
+{
+    if (ntab < 0 || ntab > MAX_TABLES) return -2;
+    if (n == 0 || ntab == 0) return 0;
+    GatherArgs a;
+    a.ntab = ntab;
+    for (int t = 0; t < ntab; ++t) { a.dst[t] = dst[t]; a.src[t] = src[t]; }
+    hipLaunchKernelGGL(k_gather_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), a, idx, idx_stride, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rhj_build_relation_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, rhj_tuple *d_tuples)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_build_relation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), d_col, d_sel, n, d_tuples);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rhj_sum_gather_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, uint64_t *sum)
+{
+    *sum = 0;
+    if (n == 0) return 0;
+    unsigned long long *d_sum = (unsigned long long *)rhj_dev_alloc(8);
+    if (!d_sum) return -1;
+    hipStream_t s = stream();
+    if (hipMemsetAsync(d_sum, 0, 8, s) != hipSuccess) return -1;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_sum_gather, dim3((unsigned)blocks), dim3(256), 0, s, d_col, d_sel, n, d_sum);
+    unsigned long long h = 0;
+    if (hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    rhj_dev_free(d_sum);
+    *sum = h;
+    return 0;
+}
+
+// ------------------------------------------------------------------ the reference's boundary, resident side
+
+rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS)
+{
+    rhj_result_tuple *out = nullptr;
+    uint64_t m = 0;
+    if (rhj_dev_join(relR->tuples, relR->num_tuples, relS->tuples, relS->num_tuples, &out, &m) < 0) die("RadixHashJoin");
+    if (m == 0) {
+        if (rhj_host_null_on_empty()) return nullptr;          // THREADS 1 behaviour
+        return make_result(rhj_dev_alloc(8), 0);               // as shipped: an empty head (rhjoin.c:356-359)
+    }
+    void *d = rhj_dev_alloc(m * sizeof(rhj_result_tuple));      // the join's own buffer is reused by the next join
+    if (!d) die("RadixHashJoin");
+    check(hipMemcpyAsync(d, out, m * sizeof(rhj_result_tuple), hipMemcpyDeviceToDevice, stream()), "copying the match list");
+    return make_result(d, m);
+}
+
+rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, rhj_relation_map *map, int *query_relations)
+{
+    const int relation = filter_p->relation;
+    const rhj_relation_map *rm = &map[query_relations[relation]];
+    const char op = filter_p->comperator;
+    if (op != '<' && op != '>' && op != '=') {                  // filter.c:184-186
+        printf("Wrong comperator in filter function\n");
+        exit(2);
+    }
+    const uint64_t *col = column_of(rm, filter_p->column);       // filter.c:96
+    rhj_inter_res *node = node_of(head, relation);               // filter.c:98-104
+    const uint64_t *sel = node ? node->data->table[relation] : nullptr;
+    const uint64_t n = node ? node->data->num_tuples : rm->num_tuples;
+    const uint64_t value = (uint64_t)(int64_t)filter_p->value;   // int -> u64, filter.c:116
+    if (n == 0) return nullptr;
+    uint64_t *ids = alloc_ids(n), hits = 0;
+    if (rhj_filter_device(col, sel, n, op, value, ids, &hits)) die("Filter");
+    if (hits == 0) { rhj_dev_free(ids); return nullptr; }        // filter.c:94,189
+    return make_result(ids, hits);
+}
+
+void rhj_resident_free_result(rhj_result *res)
+{
+    while (res) {
+        rhj_result *t = res;
+        res = res->next;
+        g_res.erase(t);
+        rhj_dev_free(t->buff);
+        free(t);
+    }
+}
+
+void rhj_resident_free_relation(rhj_relation *rel)
+{
+    g_rel.erase(rel);
+    rhj_dev_free(rel->tuples);
+    free(rel);
+}
+
+// element `index` of a resident result, for the results.c accessors (results.c:48-64, :126-142)
+int rhj_resident_fetch(const rhj_result *res, uint64_t elem_bytes, uint64_t index, void *dst)
+{
+    if (index >= res->current_load) return -1;
+    hipStream_t s = stream();
+    if (hipMemcpyAsync(dst, res->buff + index * elem_bytes, elem_bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------ inter_res.c
+
+int InitInterData(rhj_inter_data **head, int num_of_relations, int num_tuples)      // inter_res.c:10-15
+{
+    (*head) = (rhj_inter_data *)malloc(sizeof(rhj_inter_data));
+    (*head)->num_tuples = (uint64_t)num_tuples;
+    (*head)->table = (uint64_t **)calloc((size_t)num_of_relations, sizeof(uint64_t *));
+    return 0;
+}
+
+void FreeInterData(rhj_inter_data *head, int num_of_relations)                       // inter_res.c:17-24
+{
+    for (int i = 0; i < num_of_relations; ++i)
+        if (head->table[i] != nullptr) rhj_dev_free(head->table[i]);
+    free(head->table);
+    free(head);
+}
+
+int InitInterResults(rhj_inter_res **head, int num_of_rel)                           // inter_res.c:26-32
+{
+    (*head) = (rhj_inter_res *)malloc(sizeof(rhj_inter_res));
+    (*head)->next = nullptr;
+    (*head)->num_of_relations = num_of_rel;
+    InitInterData(&(*head)->data, num_of_rel, 0);
+    g_inter.insert(*head);
+    return 0;
+}
+
+void FreeInterResults(rhj_inter_res *var)                                            // inter_res.c:175-180
+{
+    if (var->next != nullptr) FreeInterResults(var->next);
+    FreeInterData(var->data, var->num_of_relations);
+    g_inter.erase(var);
+    free(var);
+}
+
+void PrintInterResults(rhj_inter_res *head)                                          // inter_res.c:154-173
+{
+    int index = 0;
+    hipStream_t s = stream();
+    while (head != nullptr) {
+        const uint64_t n = head->data->num_tuples;
+        std::vector<std::vector<uint64_t>> host((size_t)head->num_of_relations);
+        for (int j = 0; j < head->num_of_relations; ++j)
+            if (head->data->table[j] != nullptr) {
+                host[j].resize(n);
+                check(hipMemcpyAsync(host[j].data(), head->data->table[j], n * 8, hipMemcpyDeviceToHost, s), "PrintInterResults");
+            }
+        check(hipStreamSynchronize(s), "PrintInterResults");
+        printf("Intermediate results node[%d]: \n", index);
+        for (uint64_t i = 0; i < n; i++) {
+            printf("Tuple: %5lu|||||", (unsigned long)i);
+            for (int j = 0; j < head->num_of_relations; j++) {
+                if (head->data->table[j] != nullptr) printf(" %5lu |", (unsigned long)host[j][i]);
+                else printf(" NULL |");
+            }
+            printf("\n");
+        }
+        printf("--------------------------------------------------\n");
+        head = head->next;
+        index++;
+    }
+}
+
+int InsertJoinToInterResults(rhj_inter_res *head, int rel1, int rel2, rhj_result *res)   // inter_res.c:34-152
+{
+    const uint64_t count = result_count(res);
+    const uint64_t *pairs = result_ids(res);                    // {row_idR, row_idS} per element
+    TRACE("InsertJoinToInterResults rel %d %d pairs %lu", rel1, rel2, (unsigned long)count);
+    trace_nodes(head);
+    do {
+        if (head->data->num_tuples == 0) {
+            // first instance of this node: both sides of the pairs become its tables (:39-62)
+            head->data->num_tuples = count;
+            head->data->table[rel1] = alloc_ids(count);
+            head->data->table[rel2] = alloc_ids(count);
+            const uint64_t *none = nullptr;
+            gather(&head->data->table[rel1], &none, 1, pairs, 2, count);
+            gather(&head->data->table[rel2], &none, 1, pairs + 1, 2, count);
+            return 1;
+        }
+        if (head->data->table[rel1] != nullptr && head->data->table[rel2] == nullptr) {
+            // rel1 active: row_idR indexes the node's rows, row_idS is rel2's new column (:64-104)
+            rebuild_node(head, count, pairs, 2, rel2, pairs + 1);
+            return 1;
+        }
+        if (head->data->table[rel2] != nullptr && head->data->table[rel1] == nullptr) {
+            // rel2 active: the mirror case (:106-140)
+            rebuild_node(head, count, pairs + 1, 2, rel1, pairs);
+            return 1;
+        }
+        if (head->next == nullptr) break;
+        head = head->next;
+    } while (1);
+    InitInterResults(&(head->next), head->num_of_relations);   // :146-150
+    InsertJoinToInterResults(head->next, rel1, rel2, res);
+    return 0;
+}
+
+rhj_relation *ScanInterResults(int given_rel, int column, rhj_inter_res *inter, rhj_relation_map *map, int *query_relations)
+{                                                               // inter_res.c:182-206
+    rhj_inter_res *node = node_of(inter, given_rel);
+    if (node == nullptr) return nullptr;
+    const rhj_relation_map *rm = &map[query_relations[given_rel]];
+    rhj_relation *rel = (rhj_relation *)malloc(sizeof(rhj_relation));
+    rel->num_tuples = node->data->num_tuples;
+    rel->tuples = (rhj_tuple *)rhj_dev_alloc(rel->num_tuples * sizeof(rhj_tuple));
+    if (!rel->tuples) die("GetRelation");
+    if (rhj_build_relation_device(column_of(rm, column), node->data->table[given_rel], rel->num_tuples, rel->tuples)) die("GetRelation");
+    g_rel.insert(rel);
+    return rel;
+}
+
+rhj_relation *GetRelation(int given_rel, int column, rhj_inter_res *inter, rhj_relation_map *map, int *query_relations)
+{                                                               // inter_res.c:208-231
+    rhj_relation *rel = nullptr;
+    TRACE("GetRelation rel %d col %d", given_rel, column);
+    if (inter != nullptr && (rel = ScanInterResults(given_rel, column, inter, map, query_relations)) != nullptr) return rel;
+    const rhj_relation_map *rm = &map[query_relations[given_rel]];
+    rel = (rhj_relation *)malloc(sizeof(rhj_relation));
+    rel->num_tuples = rm->num_tuples;
+    rel->tuples = (rhj_tuple *)rhj_dev_alloc(rel->num_tuples * sizeof(rhj_tuple));
+    if (!rel->tuples) die("GetRelation");
+    if (rhj_build_relation_device(column_of(rm, column), nullptr, rel->num_tuples, rel->tuples)) die("GetRelation");
+    g_rel.insert(rel);
+    return rel;
+}
+
+rhj_result *SelfJoin(int given_rel, int column1, int column2, rhj_inter_res **inter, rhj_relation_map *map, int *query_relations)
+{                                                               // inter_res.c:234-263 (intended semantics, see rhj_inter.h)
+    const rhj_relation_map *rm = &map[query_relations[given_rel]];
+    const uint64_t *c1 = column_of(rm, column1), *c2 = column_of(rm, column2);
+    rhj_inter_res *node = node_of(*inter, given_rel);
+    const uint64_t *sel = node ? node->data->table[given_rel] : nullptr;
+    const uint64_t n = node ? node->data->num_tuples : rm->num_tuples;
+    if (n == 0) return nullptr;
+    uint64_t *ids = alloc_ids(n), hits = 0;
+    if (rhj_filter_eq2_device(c1, sel, c2, sel, n, ids, &hits)) die("SelfJoin");
+    if (hits == 0) { rhj_dev_free(ids); return nullptr; }
+    return make_result(ids, hits);
+}
+
+void Merge(rhj_inter_res **head, rhj_inter_res **node, int rel_num)                // inter_res.c:287-318
+{
+    rhj_inter_res *h = *head, *victim = (*node)->next;
+    const int nrel = h->num_of_relations;
+    TRACE("Merge on rel %d: head rows %lu, victim rows %lu", rel_num, (unsigned long)h->data->num_tuples, (unsigned long)victim->data->num_tuples);
+    const uint64_t n = h->data->num_tuples;
+    // head's rel_num column holds row positions of `victim`; pull every relation active there
+    std::vector<uint64_t *> dst;
+    std::vector<const uint64_t *> src;
+    for (int j = 0; j < nrel; ++j) {
+        if (victim->data->table[j] == nullptr) continue;
+        if (h->data->table[j] == nullptr) h->data->table[j] = alloc_ids(n);
+        if (j == rel_num) continue;                             // the index column itself goes last
+        dst.push_back(h->data->table[j]);
+        src.push_back(victim->data->table[j]);
+    }
+    const uint64_t *idx = h->data->table[rel_num];
+    for (size_t at = 0; at < dst.size(); at += MAX_TABLES)
+        gather(dst.data() + at, src.data() + at, (int)std::min<size_t>(MAX_TABLES, dst.size() - at), idx, 1, n);
+    {   // table[rel_num][i] = victim[rel_num][table[rel_num][i]]: element-wise in place, like the reference's loop
+        uint64_t *d = h->data->table[rel_num];
+        const uint64_t *s = victim->data->table[rel_num];
+        gather(&d, &s, 1, idx, 1, n);
+    }
+    (*node)->next = victim->next;
+    FreeInterData(victim->data, nrel);
+    g_inter.erase(victim);
+    free(victim);
+}
+
+void MergeInterNodes(rhj_inter_res **inter)                                         // inter_res.c:265-284
+{
+    if ((*inter)->next == nullptr) return;
+    for (int i = 0; i < (*inter)->num_of_relations; i++) {
+        rhj_inter_res *temp = (*inter);
+        if ((*inter)->data->table[i] == nullptr) continue;
+        while (temp->next != nullptr) {
+            if (temp->next->data->table[i] != nullptr) Merge(inter, &temp, i);
+            temp = temp->next;
+            if (temp == nullptr) break;
+        }
+    }
+    if ((*inter)->next != nullptr) MergeInterNodes(&(*inter)->next);
+}
+
+void CalculateQueryResults(rhj_inter_res *inter, rhj_relation_map *map, rhj_batch_listnode *query)   // inter_res.c:320-339
+{
+    TRACE("CalculateQueryResults");
+    trace_nodes(inter);
+    for (int i = 0; i < query->views->num_of_elements; i++) {
+        const int index = query->views->data[i][0] - '0';
+        const int relation = query->relations[index];
+        const int column = query->views->data[i][2] - '0';
+        uint64_t sum = 0;
+        if (rhj_sum_gather_device(column_of(&map[relation], column), inter->data->table[index], inter->data->num_tuples, &sum))
+            die("CalculateQueryResults");
+        printf("%lu", (unsigned long)sum);
+        if (i != query->views->num_of_elements - 1) printf(" ");
+    }
+    printf("\n");
+}
+
+void PrintNullResults(rhj_batch_listnode *query)                                    // inter_res.c:341-350
+{
+    for (int i = 0; i < query->views->num_of_elements; i++) {
+        printf("NULL");
+        if (i != query->views->num_of_elements - 1) printf(" ");
+    }
+    printf("\n");
+}
+
+int AreActiveInInter(rhj_inter_res *inter, int rel1, int rel2)                      // inter_res.c:352-361
+{
+    while (inter != nullptr) {
+        if (inter->data->table[rel1] != nullptr && inter->data->table[rel2] != nullptr) return 1;
+        inter = inter->next;
+    }
+    return 0;
+}
+
+int JoinInterNode(rhj_inter_res **inter, rhj_relation_map *rel_map, int rel1, int col1, int rel2, int col2, int *relations)
+{                                                               // inter_res.c:363-389
+    rhj_inter_res *node = (*inter);
+    while (node != nullptr) {
+        if (node->data->table[rel1] != nullptr && node->data->table[rel2] != nullptr) break;
+        node = node->next;
+    }
+    if (node == nullptr) return 0;
+    const uint64_t n = node->data->num_tuples;
+    rhj_result *res = nullptr;
+    TRACE("JoinInterNode %d.%d = %d.%d over %lu rows", rel1, col1, rel2, col2, (unsigned long)n);
+    trace_nodes(*inter);
+    if (n != 0) {
+        uint64_t *ids = alloc_ids(n), hits = 0;
+        if (rhj_filter_eq2_device(column_of(&rel_map[relations[rel1]], col1), node->data->table[rel1],
+                                  column_of(&rel_map[relations[rel2]], col2), node->data->table[rel2], n, ids, &hits))
+            die("JoinInterNode");
+        TRACE("JoinInterNode hits %lu", (unsigned long)hits);
+        if (hits == 0) rhj_dev_free(ids);
+        else res = make_result(ids, hits);                      // positions inside the node (:381)
+    }
+    InsertSingleRowIdsToInterResult(inter, rel1, res);
+    if (res) rhj_resident_free_result(res);
+    return 1;
+}
+
+void CartesianInterResults(rhj_inter_res **inter)                                   // inter_res.c:391-428
+{
+    rhj_inter_res *temp = (*inter);
+    if (temp->next == nullptr) return;
+    TRACE("CartesianInterResults");
+    CartesianInterResults(&temp->next);
+    rhj_inter_res *next_node = temp->next;
+    const uint64_t n1 = temp->data->num_tuples, n2 = next_node->data->num_tuples;
+    if (n1 * n2 == 0) return;
+    const int nrel = temp->num_of_relations;
+    rhj_inter_data *nd = nullptr;
+    InitInterData(&nd, nrel, 0);
+    nd->num_tuples = n1 * n2;
+    CartArgs c;
+    c.ntab = 0;
+    for (int z = 0; z < nrel; ++z) {
+        if (temp->data->table[z] == nullptr && next_node->data->table[z] == nullptr) continue;
+        nd->table[z] = alloc_ids(n1 * n2);
+        c.dst[c.ntab] = nd->table[z];
+        c.a[c.ntab] = temp->data->table[z];
+        c.b[c.ntab] = next_node->data->table[z];
+        if (++c.ntab == MAX_TABLES) {
+            hipLaunchKernelGGL(k_cartesian, dim3((unsigned)((n1 * n2 + 255) / 256)), dim3(256), 0, stream(), c, n1, n2);
+            c.ntab = 0;
+        }
+    }
+    if (c.ntab) hipLaunchKernelGGL(k_cartesian, dim3((unsigned)((n1 * n2 + 255) / 256)), dim3(256), 0, stream(), c, n1, n2);
+    check(hipGetLastError(), "CartesianInterResults");
+    FreeInterData(temp->data, nrel);
+    temp->data = nd;
+    FreeInterData(next_node->data, nrel);
+    g_inter.erase(next_node);
+    free(next_node);
+    temp->next = nullptr;
+}
+
+// ------------------------------------------------------------------ filter.c:11-89
+
+int InsertSingleRowIdsToInterResult(rhj_inter_res **head, int relation_num, rhj_result *res)
+{
+    const uint64_t count = result_count(res);
+    const uint64_t *ids = result_ids(res);
+    rhj_inter_res *node = *head, *last = nullptr;
+    TRACE("InsertSingleRowIdsToInterResult rel %d ids %lu", relation_num, (unsigned long)count);
+    for (; node != nullptr; last = node, node = node->next) {
+        if (node->data->num_tuples == 0) {
+            // first instance of the node: the ids are the relation's row ids (filter.c:19-40)
+            node->data->num_tuples = count;
+            node->data->table[relation_num] = alloc_ids(count);
+            const uint64_t *none = nullptr;
+            gather(&node->data->table[relation_num], &none, 1, ids, 1, count);
+            return 1;
+        }
+        if (node->data->table[relation_num] != nullptr) {
+            // already active: keep the rows the ids name, for every active relation (filter.c:42-82)
+            rebuild_node(node, count, ids, 1, -1, nullptr);
+            return 1;
+        }
+    }
+    // not active anywhere and the first node is taken: a new node at the end of the list
+    // (filter.c:83-88 dereferences the NULL it walked to; this is what it means to do)
+    InitInterResults(&last->next, last->num_of_relations);
+    return InsertSingleRowIdsToInterResult(&last->next, relation_num, res);
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 #ifndef RHJ_INTERNAL_H
 #define RHJ_INTERNAL_H
 #include "rhj.h"
+#include "rhj_inter.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -13,6 +14,21 @@ int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel,
                     uint64_t node_ids);
 int rhj_host_null_on_empty(void);
 uint64_t rhj_host_node_pairs(void);
+
+/* device-side services (rhj_device.hip) used by rhj_inter.hip */
+void *rhj_dev_alloc(size_t bytes);                 /* stream-ordered, on the library's stream */
+void  rhj_dev_free(void *p);
+void *rhj_dev_stream(void);                        /* hipStream_t */
+const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows);   /* cached device copy of a host column */
+int   rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out,
+                   uint64_t *matches);             /* *out is library-owned and valid until the next join */
+
+/* device-resident side of the reference's entry points (rhj_inter.hip), called by rhj_abi.c */
+rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS);
+rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, rhj_relation_map *map, int *query_relations);
+void rhj_resident_free_result(rhj_result *res);
+void rhj_resident_free_relation(rhj_relation *rel);
+int  rhj_resident_fetch(const rhj_result *res, uint64_t elem_bytes, uint64_t index, void *dst);
 #ifdef __cplusplus
 }
 #endif

@@ -2127,6 +2127,39 @@ __global__ __launch_bounds__(256) void k_filter_mask(const uint64_t *col, const 
     if (threadIdx.x == 0) tile_count[blockIdx.x] = (uint64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// Two-column equality (SelfJoin / JoinInterNode, inter_res.c:234-263, :363-389): same mask layout as
+// k_filter_mask, predicate colA[selA ? selA[i] : i] == colB[selB ? selB[i] : i].
+__global__ __launch_bounds__(256) void k_filter_mask_eq2(const uint64_t *colA, const uint64_t *selA, const uint64_t *colB,
+                                                         const uint64_t *selB, uint64_t n, uint64_t *masks, uint64_t *tile_count)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t wbase = (uint64_t)blockIdx.x * FILTER_TILE + (uint64_t)w * FILTER_WAVE_ELEMS;
+    uint64_t a0[FILTER_ROUNDS], a1[FILTER_ROUNDS], b0[FILTER_ROUNDS], b1[FILTER_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < FILTER_ROUNDS; ++k) {
+        const uint64_t i = wbase + (uint64_t)k * 2 * WAVE + 2 * lane;
+        a0[k] = a1[k] = 0; b0[k] = b1[k] = 1;
+        if (i < n)     { a0[k] = colA[selA ? selA[i] : i];         b0[k] = colB[selB ? selB[i] : i]; }
+        if (i + 1 < n) { a1[k] = colA[selA ? selA[i + 1] : i + 1]; b1[k] = colB[selB ? selB[i + 1] : i + 1]; }
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < FILTER_ROUNDS; ++k) {
+        const uint64_t i = wbase + (uint64_t)k * 2 * WAVE + 2 * lane;
+        const uint64_t me = __ballot(i < n && a0[k] == b0[k]);
+        const uint64_t mo = __ballot(i + 1 < n && a1[k] == b1[k]);
+        if (lane == 0 && wbase + (uint64_t)k * 2 * WAVE < n) {
+            masks[(wbase >> 6) + 2 * k] = me;
+            masks[(wbase >> 6) + 2 * k + 1] = mo;
+        }
+        cnt += (uint32_t)__popcll(me) + (uint32_t)__popcll(mo);
+    }
+    if (lane == 0) wsum[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = (uint64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // Pass 2: turn the masks into the ascending index list.
 __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t *masks, const uint64_t *tile_base,
                                                       uint64_t *out)

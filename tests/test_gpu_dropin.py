@@ -1,8 +1,13 @@
 """GPU: the reference's own engine (its caller side compiled unchanged in the build
-container and linked against librhj.so: oracle/_ref/radixhash_rhj, see oracle/Makefile and
-INTEGRATION.md) answers the SIGMOD'18 `small` workload with our RadixHashJoin()/Filter()
-doing the hot path, and must reproduce the reference's golden file small.result line by
-line.  The relation files are rebuilt from the committed fixture."""
+container and linked against librhj.so, see oracle/Makefile and INTEGRATION.md) answers the
+SIGMOD'18 `small` workload and must reproduce the reference's golden file small.result line
+by line.  Two link configurations:
+  radixhash_rhj           our RadixHashJoin()/Filter() behind the reference's inter_res.c
+                          (host-resident intermediate results, H2D/D2H per operator);
+  radixhash_rhj_resident  inter_res.c and filter.c left out: librhj.so supplies their whole
+                          interface with the intermediate results kept on the device
+                          (include/rhj_inter.h).
+The relation files are rebuilt from the committed fixture."""
 import os
 import subprocess
 
@@ -12,12 +17,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENGINE = os.path.join(ROOT, "oracle", "_ref", "radixhash_rhj")
+ENGINES = {name: os.path.join(ROOT, "oracle", "_ref", name) for name in ("radixhash_rhj", "radixhash_rhj_resident")}
 
 
-@pytest.mark.skipif(not os.path.exists(ENGINE), reason="oracle/_ref/radixhash_rhj not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("engine", sorted(ENGINES))
 @pytest.mark.parametrize("empty_mode", ["head", "null"])
-def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode):
+def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode, engine):
+    ENGINE = ENGINES[engine]
+    if not os.path.exists(ENGINE):
+        pytest.skip("oracle/_ref/%s not built (needs /root/reference at build time)" % engine)
     rels = golden.small_relations
     names = []
     for i in range(14):

@@ -25,14 +25,19 @@ def lib(mod):
     return mod.load_library()
 
 
-def test_exports_every_declared_symbol(mod, lib):
-    hdr = open(os.path.join(ROOT, "include", "rhj.h")).read()
+def declared_in(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = hdr.split("#ifdef RHJ_REFERENCE_NAMES")[0]
     hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)                 # comments out
-    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{()]*\)\s*;", hdr))
-    assert declared == set(mod.ABI_SYMBOLS), declared ^ set(mod.ABI_SYMBOLS)
-    for name in declared:
-        assert hasattr(lib, name), name
+    return set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{()]*\)\s*;", hdr))
+
+
+def test_exports_every_declared_symbol(mod, lib):
+    for header, names in (("rhj.h", mod.ABI_SYMBOLS), ("rhj_inter.h", mod.INTER_SYMBOLS)):
+        declared = declared_in(header)
+        assert declared == set(names), (header, declared ^ set(names))
+        for name in declared:
+            assert hasattr(lib, name), name
 
 
 def test_layouts_match_the_reference_structs(mod):

@@ -16,7 +16,7 @@ for i in range(14):
     names.append("r%d" % i)
 stdin = ("\n".join(names) + "\nDone\n" + "\n".join(g.small["work_lines"]) + "\n").encode()
 out = {}
-for exe in ("radixhash_t1", "radixhash_t4", "radixhash_rhj"):
+for exe in ("radixhash_t1", "radixhash_t4", "radixhash_rhj", "radixhash_rhj_resident"):
     path = os.path.join("oracle", "_ref", exe)
     if not os.path.exists(path):
         continue
