@@ -127,7 +127,6 @@ int ctx_init()
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
     // dynamic LDS above 64 KiB has to be requested per kernel
     HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_hist_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -163,9 +162,8 @@ size_t scatter_runs_lds_bytes(int bits)
     return (size_t)PT_TILE * 16 + (PT_WAVES + 3) * bins * 4 + (PT_BLOCK / 64 + 2) * 8 + (2 * PT_MAX_GROUP + 1) * 4 + 16;
 }
 
-// one stable pass over both relations: per-tile histogram, scan, LDS-staged scatter
-int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int full_bits, uint64_t *hist, uint64_t *psum,
-                   bool first, int next_shift = 0, int next_bits = 0)
+// one stable pass over both relations (radix bits <= 8): per-tile histogram, scan, LDS-staged scatter
+int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, uint64_t *psum)
 {
     const uint32_t bins = 1u << bits;
     uint32_t max_tiles = r0.tiles;
@@ -175,20 +173,17 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int shift, int bits, int fu
     if (chunks < 1) chunks = 1;
     if (ensure(g.chunk, (size_t)2 * chunks * bins * 8)) return -1;
     const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
-    const size_t hist_lds = ((size_t)bins + (full_bits ? ((size_t)1 << full_bits) : 0)) * 4;
-    if (first) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(hist_lds > 32 * 1024 ? 1024 : 256), hist_lds, g.stream, r0, r1,
-               shift, bits, full_bits, (uint32_t *)g.fullhist.p);
-    if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
+    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
     RHJ_LAUNCH(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (uint64_t *)g.chunk.p);
     RHJ_LAUNCH(k_scan_bins, dim3(bins, nrel), dim3(WAVE), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist);
     RHJ_LAUNCH(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint64_t *)hist, psum);
     RHJ_LAUNCH(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
-    if (first) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
-    RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1,
-                       shift, bits, next_shift, next_bits);
+    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -216,7 +211,7 @@ int run_partition(PartState &ps, int bits, int nrel)
         ps.r[1].cnt = (uint32_t *)g.cntS.p;
     }
     if (bits <= PT_MAX_BITS)
-        return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, 0, bits, 0, ps.hist, ps.psum, true);
+        return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, bits, ps.hist, ps.psum);
 
     // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
     const int lo = bits / 2, hi = bits - lo;

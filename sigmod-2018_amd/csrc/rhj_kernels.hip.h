@@ -49,8 +49,8 @@ struct RelArgs {                 // one relation through one partition pass
     uint64_t         n;
     uint32_t         tiles;
     uint32_t         pad;
-    const uint8_t   *dig_in;     // pass 2: this pass' digit per input tuple, written by pass 1 (else null)
-    uint8_t         *dig_out;    // pass 1 of a two-pass partition: next pass' digit per OUTPUT tuple (else null)
+    const uint8_t   *dig_in;     // pass 2 of the run form: this pass' digit per input tuple, written by pass 1
+    uint8_t         *dig_out;    // pass 1 of the run form: the next pass' digit per output tuple
     // two-pass partition (run form): pass 1 partitions every tile in place and leaves a run table;
     // a pass-2 tile is `group` consecutive pass-1 tiles' runs of one pass-1 digit
     uint16_t        *runs;       // [bins1 + 1][tiles1] start of each digit's run inside its pass-1 tile; row bins1 = the tile's count
@@ -166,54 +166,27 @@ constexpr int PT_WAVES = PT_BLOCK / WAVE;
 constexpr int PT_MAX_BITS = 8;                    // digit bits per pass
 constexpr uint32_t PT_MAX_GROUP = 256;            // pass-1 tiles per pass-2 tile (run form), at most
 
-// Per-tile digit histogram of one pass: cnt[tile][digit] for digit = (key >> shift) & mask.
-// full_bits > 0 additionally accumulates the histogram of the low full_bits bits of the
-// key (the join's bucket histogram) into full_hist with one atomic per bin per workgroup.
-__global__ __launch_bounds__(1024) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits, int full_bits,
-                                                    uint32_t *full_hist /*[2][1<<full_bits]*/)
+// Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
+__global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits)
 {
     extern __shared__ uint32_t lds_u32[];
-    const uint32_t nt = blockDim.x;               // 256, or 1024 when the 2^full_bits table limits the CU to 2 workgroups
     const RelArgs &r = blockIdx.y ? r1 : r0;
     const uint32_t bins = 1u << bits, mask = bins - 1u;
-    const uint32_t fbins = full_bits ? 1u << full_bits : 0u, fmask = fbins - 1u;
     uint32_t *tile_h = lds_u32;                   // [bins]
-    uint32_t *full_h = lds_u32 + bins;            // [fbins]
-    for (uint32_t b = threadIdx.x; b < fbins; b += nt) full_h[b] = 0;
     for (uint32_t tile = blockIdx.x; tile < r.tiles; tile += gridDim.x) {
-        for (uint32_t b = threadIdx.x; b < bins; b += nt) tile_h[b] = 0;
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) tile_h[b] = 0;
         __syncthreads();
         const uint64_t beg = (uint64_t)tile * PT_TILE;
         const uint64_t end = min(beg + (uint64_t)PT_TILE, r.n);
-        if (r.dig_in) {                               // digits were precomputed by the previous pass: 1 B per tuple
-            const uint32_t *d4 = reinterpret_cast<const uint32_t *>(r.dig_in + beg);
-            const uint32_t cnt = (uint32_t)(end - beg);
-            for (uint32_t j = threadIdx.x; j < (cnt + 3) / 4; j += nt) {
-                const uint32_t v = d4[j];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (4 * j + t < cnt) atomicAdd(&tile_h[(v >> (8 * t)) & 0xffu], 1u);
-            }
-        } else {
 #pragma unroll 4
-            for (uint64_t i = beg + threadIdx.x; i < end; i += nt) {
-                const uint32_t k = (uint32_t)r.in[i].value;       // shift + bits and full_bits <= 16
-                atomicAdd(&tile_h[(k >> shift) & mask], 1u);
-                if (full_bits) atomicAdd(&full_h[k & fmask], 1u);
-            }
+        for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+            const uint32_t k = (uint32_t)(r.in[i].value >> shift);
+            atomicAdd(&tile_h[k & mask], 1u);
         }
         __syncthreads();
         uint32_t *row = r.cnt + (size_t)tile * bins;
-        for (uint32_t b = threadIdx.x; b < bins; b += nt) row[b] = tile_h[b];
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) row[b] = tile_h[b];
         __syncthreads();
-    }
-    if (full_bits) {
-        __syncthreads();
-        uint32_t *dst = full_hist + (size_t)blockIdx.y * fbins;
-        for (uint32_t b = threadIdx.x; b < fbins; b += nt) {
-            const uint32_t v = full_h[b];
-            if (v) atomicAdd(&dst[b], v);
-        }
     }
 }
 
@@ -316,8 +289,7 @@ __global__ __launch_bounds__(1024) void k_full_psum(int bits, const uint32_t *fu
 //   wave) + (same digit in lower lanes of this round)
 // computed with one match-any (bits ballots) per round and per-wave LDS counters — no
 // atomics, so the placement does not depend on any hardware ordering.
-__global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift,
-                                                          int next_bits)
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
@@ -404,7 +376,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
             const uint32_t d = (v.x >> shift) & mask;
             const uint32_t dst = delta[d] + p;
             out[dst] = v;
-            if (r.dig_out) r.dig_out[dst] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
         }
     }
 }
@@ -1353,7 +1324,7 @@ __device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V],
 constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
 template <bool RES>
 __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, uint32_t bc, uint4 *ltup,
-                                         uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick, uint64_t *dbgu)
+                                         uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
@@ -1392,7 +1363,6 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
         }
     }
     __syncthreads();
-    if (dbgu && threadIdx.x == 0) dbgu[5] = __builtin_amdgcn_s_memrealtime();
     // ---- exclusive scan over the halfwords: H[s + 1] = start of slot s, H[hs + 1] = bc
     {
         const uint32_t chunk = (ndw + FJ_BLOCK - 1u) / FJ_BLOCK;
@@ -1412,7 +1382,6 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
         }
     }
     __syncthreads();
-    if (dbgu && threadIdx.x == 0) dbgu[6] = __builtin_amdgcn_s_memrealtime();
     // ---- fill.  Ordered insertion into the slot's range: atomicMax on the cell, go on with the
     // smaller of the two values; exactly n values enter n cells, so a carry always finds an empty cell
     // inside the range.  Long slots (many duplicates of one key, where that would be quadratic) take
@@ -1459,7 +1428,6 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
             for (int k = 0; k < FJ_V; ++k) t[k] = tn[k];
         }
     }
-    if (dbgu && threadIdx.x == 0) dbgu[7] = __builtin_amdgcn_s_memrealtime();
     if (__syncthreads_or(has_long)) {
         // long slots: one at a time, ranked by the whole workgroup (descending value)
         for (uint32_t next = 0;;) {
@@ -1780,7 +1748,6 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
     uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
-    const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
     FjGather G;
     G.init(bd, bc);
     FjOvf O;                                          // double-buffered: the previous unit's emit may still be pending
@@ -1791,8 +1758,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
-    if (RES) fj_build<true>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick, f.dbg ? f.dbg + (size_t)u * 8 : nullptr);
-    else     fj_build<false>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick, f.dbg ? f.dbg + (size_t)u * 8 : nullptr);
+    if (RES) fj_build<true>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
+    else     fj_build<false>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
     if (a.ablate == 1) continue;                      // timing experiment: build only
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
@@ -1866,7 +1833,6 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         pend = 0xffffffffu;
         __syncthreads();
     }
-    if (false && f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 6] = (unit_needs_index ? 1u : 0u) | (RES ? 2u : 0u) | (emitting ? 4u : 0u) | ((uint64_t)total << 8);
     if (emitting && !RES && !unit_needs_index) {      // this unit's emit pass needs no index: defer it
         pend = u;
         pend_total = total;
@@ -1894,10 +1860,6 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     // round, lane).  FJ_H = 2 (more loads in flight, half the barriers) measured +11 % on the kernel:
     // it spills at the 128-VGPR limit of a 1024-thread workgroup.
     constexpr int FJ_H = 1;
-    uint32_t dt_load = 0, dt_scan = 0, dt_walk = 0;
-    uint64_t tm = 0;
-#define FJ_STAMP(acc) if (f.dbg) { __builtin_amdgcn_s_waitcnt(0); const uint64_t now_ = __builtin_amdgcn_s_memrealtime(); acc += (uint32_t)(now_ - tm); tm = now_; }
-    if (f.dbg) tm = __builtin_amdgcn_s_memrealtime();
     for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_H * FJ_BATCH) {
         uint32_t c[FJ_H][FJ_V], flo[FJ_H][FJ_V], fhi[FJ_H][FJ_V];
         uint4 q[FJ_H][FJ_V];
@@ -1940,7 +1902,6 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 }
             }
         }
-        FJ_STAMP(dt_load)
         uint32_t off[FJ_H][FJ_V], wrun = 0;
 #pragma unroll
         for (int h = 0; h < FJ_H; ++h) {
@@ -1963,7 +1924,6 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             batch_total += v;
         }
         run += batch_total;
-        FJ_STAMP(dt_scan)
         // The first match comes from the stash (phase 1 kept its row id).  Further matches of a tuple
         // are fetched in lockstep rounds over its chain; when no tag hit of the tuple was a foreign key
         // (the rule: stash bit 7 clear) its first candidate IS that first match and is skipped unfetched.
@@ -2005,10 +1965,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 }
             }
         }
-        FJ_STAMP(dt_walk)
     }
     if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-    if (false && f.dbg && threadIdx.x == 64) { f.dbg[(size_t)u * 8 + 7] = ((uint64_t)dt_load << 32) | dt_scan; f.dbg[(size_t)u * 8 + 5] = dt_walk; }
     }   // ticket loop
 
     if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup
