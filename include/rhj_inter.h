@@ -16,7 +16,8 @@
  * The structs themselves, `num_tuples`, `current_load`, `next` and the NULL-ness of
  * `table[rel]` stay host-readable, which is all the reference's query.c looks at
  * (query.c:334-465).  A maintainer switches the engine to this mode by NOT compiling
- * inter_res.c and filter.c and linking librhj.so instead; with the
+ * inter_res.c and filter.c (and, for device-side loading and statistics, relation_map.c)
+ * and linking librhj.so instead; with the
  * reference's own inter_res.c in the link these definitions are simply never called and
  * RadixHashJoin()/Filter() keep their host-memory behaviour.  RadixHashJoin(), Filter(),
  * FreeRelation(), FreeResult() and GetResultNum() recognise device-resident arguments by
@@ -89,6 +90,20 @@ void CartesianInterResults(rhj_inter_res **inter);
 /* filter.h:15 (filter.c:11-89) */
 int  InsertSingleRowIdsToInterResult(rhj_inter_res **head, int relation_num, rhj_result *res);
 
+/* relation_map.h:10-16: map the relation files (header u64 tuples, u64 columns,
+ * then column-major u64 data, relation_map.c:39-50), copy every column to the device once — the
+ * copies Filter()/GetRelation()/CalculateQueryResults() use — and compute the optimiser's column
+ * statistics there: l = min, u = max, f = tuples, d = distinct values counted with the reference's
+ * flag array including its cap (range above 50 000 000 folds modulo 5 000 000, relation_map.c:66-84). */
+typedef struct rhj_relation_listnode {       /* structs.h:86-91 */
+    char                         *filename;
+    int                           fd;
+    struct rhj_relation_listnode *next;
+} rhj_relation_listnode;
+int  InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map);   /* relation_map.c:13-88  */
+void FreeRelationMap(rhj_relation_map *rel_map, int map_size);                   /* relation_map.c:90-98  */
+void PrintRelationMap(rhj_relation_map *rel_map, int map_size);                  /* relation_map.c:100-115 */
+
 /* ---- device entry points behind them (tests and bench call these directly) ---------- */
 
 /* dst[t][i] = src[t][idx[i * idx_stride]] for t < ntab (idx_stride 2 walks one side of a pair
@@ -102,6 +117,8 @@ int rhj_sum_gather_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t
 /* ascending i with colA[selA ? selA[i] : i] == colB[selB ? selB[i] : i] */
 int rhj_filter_eq2_device(const uint64_t *d_colA, const uint64_t *d_selA, const uint64_t *d_colB, const uint64_t *d_selB,
                           uint64_t n, uint64_t *d_out, uint64_t *hits);
+/* min, max and the reference's distinct-value estimate of a device column (n >= 1) */
+int rhj_column_stats_device(const uint64_t *d_col, uint64_t n, uint64_t *l, uint64_t *u, double *d);
 
 /* 1 when the object was created by this library's device-resident side */
 int rhj_resident_relation(const rhj_relation *rel);

@@ -8,6 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <unordered_set>
 #include <vector>
 
@@ -72,6 +76,50 @@ __global__ __launch_bounds__(256) void k_cartesian(CartArgs c, uint64_t n1, uint
     if (x >= n1 * n2) return;
     const uint64_t i = x / n2, j = x % n2;
     for (int t = 0; t < c.ntab; ++t) c.dst[t][x] = c.a[t] ? c.a[t][i] : c.b[t][j];
+}
+
+// column statistics (relation_map.c:53-84): min / max, then one flag per value of the range
+__global__ __launch_bounds__(256) void k_col_minmax(const uint64_t *col, uint64_t n, unsigned long long *mm /*[min, max]*/)
+{
+    __shared__ unsigned long long lo4[4], hi4[4];
+    unsigned long long lo = ~0ull, hi = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long v = col[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { lo4[threadIdx.x >> 6] = lo; hi4[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { lo = lo4[w] < lo ? lo4[w] : lo; hi = hi4[w] > hi ? hi4[w] : hi; }
+        lo = lo4[0] < lo ? lo4[0] : lo; hi = hi4[0] > hi ? hi4[0] : hi;
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+__global__ __launch_bounds__(256) void k_col_flags(const uint64_t *col, uint64_t n, uint64_t lo, uint64_t fold, uint8_t *flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = col[i] - lo;
+    flags[fold ? x % fold : x] = 1;                  // everybody stores the same byte
+}
+__global__ __launch_bounds__(256) void k_count_flags(const uint8_t *flags, uint64_t n, unsigned long long *count)
+{
+    __shared__ unsigned long long part[4];
+    unsigned long long s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) s += flags[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, part[0] + part[1] + part[2] + part[3]);
 }
 
 std::unordered_set<const void *> g_rel, g_res, g_inter;
@@ -608,6 +656,95 @@ int InsertSingleRowIdsToInterResult(rhj_inter_res **head, int relation_num, rhj_
     // (filter.c:83-88 dereferences the NULL it walked to; this is what it means to do)
     InitInterResults(&last->next, last->num_of_relations);
     return InsertSingleRowIdsToInterResult(&last->next, relation_num, res);
+}
+
+
+// ------------------------------------------------------------------ relation_map.c
+
+int rhj_column_stats_device(const uint64_t *d_col, uint64_t n, uint64_t *l, uint64_t *u, double *d)
+{
+    if (n == 0) { *l = *u = 0; *d = 0; return 0; }
+    hipStream_t s = stream();
+    unsigned long long *acc = (unsigned long long *)rhj_dev_alloc(32);      // min, max, count
+    if (!acc) return -1;
+    const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+    unsigned long long h[3];
+    if (hipMemcpyAsync(acc, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_col_minmax, dim3((unsigned)blocks), dim3(256), 0, s, d_col, n, acc);
+    if (hipMemcpyAsync(h, acc, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    *l = h[0]; *u = h[1];
+    // relation_map.c:66-84: one flag per value of [l, u], at most 50 000 000 flags; a larger (or exactly that
+    // large) range is folded modulo 5 000 000 into the same 50 000 000-entry array before counting
+    uint64_t size = h[1] - h[0] + 1;
+    if (size > 50000000ull || size == 0) size = 50000000ull;
+    const uint64_t fold = size < 50000000ull ? 0 : 5000000ull;
+    uint8_t *flags = (uint8_t *)rhj_dev_alloc(size);
+    if (!flags) return -1;
+    if (hipMemsetAsync(flags, 0, size, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_col_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_col, n, h[0], fold, flags);
+    uint64_t cb = (size + 255) / 256;
+    if (cb > 2048) cb = 2048;
+    hipLaunchKernelGGL(k_count_flags, dim3((unsigned)cb), dim3(256), 0, s, flags, size, acc + 2);
+    if (hipMemcpyAsync(h + 2, acc + 2, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    *d = (double)h[2];
+    rhj_dev_free(flags);
+    rhj_dev_free(acc);
+    return 0;
+}
+
+int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)           // relation_map.c:13-88
+{
+    int i = 0;
+    while (head != nullptr) {
+        struct stat sb;
+        if ((head->fd = open(head->filename, O_RDONLY)) == -1) return 1;
+        if (fstat(head->fd, &sb) == -1) return 1;
+        uint64_t *map = (uint64_t *)mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, head->fd, 0);
+        if (map == MAP_FAILED) {
+            printf("map failed \n");
+            return 1;
+        }
+        rel_map[i].num_tuples = map[0];
+        rel_map[i].num_columns = map[1];
+        rel_map[i].col_stats = (rhj_column_stats *)malloc(rel_map[i].num_columns * sizeof(rhj_column_stats));
+        rel_map[i].columns = (uint64_t **)malloc(rel_map[i].num_columns * sizeof(uint64_t *));
+        map = map + 2;
+        for (uint64_t j = 0; j < rel_map[i].num_columns; ++j) {
+            rel_map[i].columns[j] = map;
+            map += rel_map[i].num_tuples;
+            // the device copy every later operator reads, and the statistics computed on it
+            const uint64_t *d_col = column_of(&rel_map[i], (int)j);
+            rhj_column_stats *st = &rel_map[i].col_stats[j];
+            st->f = (double)rel_map[i].num_tuples;
+            if (rhj_column_stats_device(d_col, rel_map[i].num_tuples, &st->l, &st->u, &st->d)) die("InitRelationMap");
+        }
+        head = head->next;
+        i++;
+    }
+    return 0;
+}
+
+void FreeRelationMap(rhj_relation_map *rel_map, int map_size)                        // relation_map.c:90-98
+{
+    for (int i = 0; i < map_size; ++i) {
+        free(rel_map[i].columns);
+        free(rel_map[i].col_stats);
+    }
+    free(rel_map);
+}
+
+void PrintRelationMap(rhj_relation_map *rel_map, int map_size)                       // relation_map.c:100-115
+{
+    for (int i = 0; i < map_size; ++i) {
+        printf("Printing Relation: %d\n", i);
+        printf("%lu %lu\n", (unsigned long)rel_map[i].num_tuples, (unsigned long)rel_map[i].num_columns);
+        for (uint64_t j = 0; j < rel_map[i].num_columns; ++j) {
+            printf("Printing Column: %d\n", (int)j);
+            for (uint64_t k = 0; k < rel_map[i].num_tuples; ++k) printf(" %lu\n", (unsigned long)rel_map[i].columns[j][k]);
+        }
+    }
 }
 
 }  // extern "C"

@@ -266,3 +266,74 @@ def test_scripted_plans_match_the_reference_host_code(mod, rhj):
             assert s.value == int(col[ids].sum(dtype=np.uint64)), (name, j)
         for e in engines:
             e.L.FreeInterResults(e.head)
+
+
+# ------------------------------------------------------------------ (3) relation loading and column statistics
+
+class ListNode(C.Structure):
+    pass
+
+
+ListNode._fields_ = [("filename", C.c_char_p), ("fd", C.c_int), ("next", C.POINTER(ListNode))]
+
+
+def flag_count(col):
+    """relation_map.c:66-84 in numpy"""
+    lo, hi = int(col.min()), int(col.max())
+    size = min(hi - lo + 1, 50_000_000)
+    x = (col - np.uint64(lo)).astype(np.uint64)
+    idx = x if size < 50_000_000 else x % np.uint64(5_000_000)
+    return lo, hi, float(len(np.unique(idx)))
+
+
+def test_column_stats_device(rhj):
+    lib = rhj.lib
+    lib.rhj_column_stats_device.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(21)
+    cols = {
+        "dense": rng.integers(1000, 9000, 300_000, dtype=np.uint64),
+        "wide (folded modulo 5e6)": rng.integers(0, 1 << 40, 200_000, dtype=np.uint64),
+        "exactly 5e7 (folded)": np.concatenate([np.array([7, 7 + 49_999_999], dtype=np.uint64),
+                                                 rng.integers(7, 7 + 50_000_000, 100_000, dtype=np.uint64)]),
+        "constant": np.full(1000, 42, dtype=np.uint64),
+        "one row": np.array([5], dtype=np.uint64),
+    }
+    for name, col in cols.items():
+        d = dev(rhj, col)
+        l, u, dd = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+        assert lib.rhj_column_stats_device(d.data_ptr(), len(col), C.byref(l), C.byref(u), C.byref(dd)) == 0
+        assert (l.value, u.value, dd.value) == flag_count(col), name
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/libref_n4_t1.so not built (needs /root/reference at build time)")
+def test_init_relation_map_matches_the_reference(mod, rhj, golden, tmp_path):
+    ref = C.CDLL(REF)
+    files = []
+    for i in range(14):
+        cols = golden.small_relations["r%d" % i].astype("<u8")
+        path = tmp_path / ("r%d" % i)
+        with open(path, "wb") as f:
+            np.array([cols.shape[1], cols.shape[0]], dtype="<u8").tofile(f)
+            cols.tofile(f)
+        files.append(str(path).encode())
+    got = []
+    for lib in (ref, rhj.lib):
+        nodes = (ListNode * len(files))()
+        for k, fn in enumerate(files):
+            nodes[k].filename = fn
+            nodes[k].fd = -1
+            nodes[k].next = C.pointer(nodes[k + 1]) if k + 1 < len(files) else None
+        rm = (mod.RelationMap * len(files))()
+        lib.InitRelationMap.argtypes = [C.POINTER(ListNode), C.POINTER(mod.RelationMap)]
+        lib.InitRelationMap(nodes, rm)
+        stats = []
+        for r in range(len(files)):
+            assert rm[r].num_tuples == golden.small_relations["r%d" % r].shape[1]
+            assert rm[r].num_columns == golden.small_relations["r%d" % r].shape[0]
+            for c in range(rm[r].num_columns):
+                st = rm[r].col_stats[c]
+                stats.append((st.l, st.u, st.f, st.d))
+                col = np.ctypeslib.as_array(C.cast(rm[r].columns[c], u64p), (rm[r].num_tuples,))
+                assert np.array_equal(col, golden.small_relations["r%d" % r][c])
+        got.append(stats)
+    assert got[0] == got[1]
