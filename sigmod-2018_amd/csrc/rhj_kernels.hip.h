@@ -1322,6 +1322,7 @@ __device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V],
 // on the way and the second pass reads them there.  `tmp` is global scratch of at least 4 * bc bytes
 // for the cooperative sort of long slots.
 constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
+constexpr int FJ_SMALL = 4;                           // batches of 4096 build tuples whose (slot, tag) words are kept for the fill pass
 template <bool RES>
 __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, uint32_t bc, uint4 *ltup,
                                          uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
@@ -1333,7 +1334,10 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
     for (uint32_t i = tid; i < bc; i += FJ_BLOCK) X.ent[i] = 0;
     if (tid < 8) X.ent[bc + tid] = 0xffff0000u;
     __syncthreads();
-    // ---- count: H[s + 1] += 1
+    // ---- count: H[s + 1] += 1.  Build sides of up to 4 batches (16 K tuples) are hashed only once: the
+    // (slot, tag) word of tuple i is parked in ent[i], picked up into registers before the fill pass
+    // clears the array, and the fill pass needs neither the key nor a second hash.
+    const bool small = bc <= FJ_SMALL * FJ_BATCH;
     {
         uint4 t[FJ_V], tn[FJ_V];                       // current and prefetched batch of build tuples
 #pragma unroll
@@ -1354,7 +1358,10 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
                 const uint32_t i = i0 + k * FJ_BLOCK + tid;
                 if (i < bc) {
                     if (RES) ltup[i] = t[k];
-                    const uint32_t j = X.slot(mix64(((uint64_t)t[k].y << 32) | t[k].x)) + 1u;
+                    const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
+                    const uint32_t sl = X.slot(h);
+                    if (small) X.ent[i] = (sl << 16) | fj_tag(h);       // parked in the still unused entry array
+                    const uint32_t j = sl + 1u;
                     atomicAdd(&X.dirw[j >> 1], (j & 1u) ? 0x10000u : 1u);
                 }
             }
@@ -1388,7 +1395,46 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
     // places in arrival order — the range's last cell counts the arrivals until the last arrival
     // overwrites it — and are ranked afterwards.
     bool has_long = false;
-    {
+    auto insert = [&](uint32_t sl, uint32_t v) {
+        const uint32_t a = X.H(sl + 1u), n = X.H(sl + 2u) - a;
+        if (n <= FJ_LONG) {
+            for (uint32_t p = a;; ++p) {
+                const uint32_t old = atomicMax(&X.ent[p], v);
+                if (old == 0) break;
+                v = min(old, v);
+            }
+        } else {
+            has_long = true;
+            const uint32_t arrival = atomicAdd(&X.ent[a + n - 1u], 1u);
+            X.ent[a + arrival] = v;                  // arrival n - 1: everybody has counted, the counter cell is free
+        }
+    };
+    if (small) {
+        uint32_t hw[FJ_SMALL][FJ_V];
+#pragma unroll
+        for (int b = 0; b < FJ_SMALL; ++b)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = (uint32_t)b * FJ_BATCH + k * FJ_BLOCK + tid;
+                hw[b][k] = i < bc ? X.ent[i] : 0;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < FJ_SMALL; ++b)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = (uint32_t)b * FJ_BATCH + k * FJ_BLOCK + tid;
+                if (i < bc) X.ent[i] = 0;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < FJ_SMALL; ++b)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = (uint32_t)b * FJ_BATCH + k * FJ_BLOCK + tid;
+                if (i < bc) insert(hw[b][k] >> 16, (hw[b][k] << 16) | i);
+            }
+    } else {
         uint4 t[FJ_V], tn[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
@@ -1408,20 +1454,7 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
                 const uint32_t i = i0 + k * FJ_BLOCK + tid;
                 if (i < bc) {
                     const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
-                    const uint32_t sl = X.slot(h);
-                    const uint32_t a = X.H(sl + 1u), n = X.H(sl + 2u) - a;
-                    uint32_t v = (fj_tag(h) << 16) | i;
-                    if (n <= FJ_LONG) {
-                        for (uint32_t p = a;; ++p) {
-                            const uint32_t old = atomicMax(&X.ent[p], v);
-                            if (old == 0) break;
-                            v = min(old, v);
-                        }
-                    } else {
-                        has_long = true;
-                        const uint32_t arrival = atomicAdd(&X.ent[a + n - 1u], 1u);
-                        X.ent[a + arrival] = v;      // arrival n - 1: everybody has counted, the counter cell is free
-                    }
+                    insert(X.slot(h), (fj_tag(h) << 16) | i);
                 }
             }
 #pragma unroll
