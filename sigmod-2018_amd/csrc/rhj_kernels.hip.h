@@ -1191,19 +1191,20 @@ __global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
 
 // ------------------------------------------------------------- fused LDS join
 //
-// One workgroup per unit = (bucket, up to FJ_SPAN probe tuples), taken in canonical order
-// through a ticket so that a unit's predecessors are always running or done.
-//   build    ordered 32-bit table of the bucket's build side in LDS
-//   phase 1  stream the unit's probe tuples; chain walk in LDS; ONE global gather per
-//            candidate (key to verify + row id); per probe tuple stash the match count
-//            (u8) and the first match's build row id (u64), coalesced
-//            (RES variant, build side <= ~7 K tuples: the build tuples themselves are
-//            copied into LDS during the build, so there is no global gather and no stash;
-//            phase 2 simply probes the LDS index again)
-//   chain    publish the unit's match total, decoupled look-back over the predecessors
-//            (one 8-byte {flag,value} word per unit, agent-scope relaxed atomics)
-//   phase 2  stream probe row ids + stash and write the pairs at their final canonical
-//            positions; only tuples with two or more matches walk the table again
+// One persistent workgroup per CU takes units = (bucket, up to FJ_SPAN probe tuples) in canonical
+// order through a ticket, so that a unit's predecessors are always running or done.
+//   build    CSR slot index of the bucket's build side in LDS (fj_build)
+//   phase 1  stream the unit's probe keys; one 8-entry tag window per tuple in LDS; ONE global
+//            gather per candidate (key to verify + row id) — from LDS instead when the build
+//            tuples fit there too (RES, build side <= ~7 K tuples); per probe tuple stash the
+//            match count (u8) and the first match's build row id (u64), further matches go to
+//            the overflow stash (fj_count_batch)
+//   chain    publish the unit's match total right away (8-byte {flag,value} word per unit,
+//            agent-scope relaxed atomics)
+//   emit     deferred behind the NEXT unit's build and phase 1: decoupled look-back over the
+//            predecessors (never waits by then), then stream probe row ids + stash + overflow
+//            stash and write the pairs at their final canonical positions (fj_emit_stream).
+//            Units the overflow stash cannot describe emit immediately by walking the index again.
 // Random global accesses per probe tuple: one 128-byte line (the gather); everything
 // else is streaming or LDS.
 constexpr int FJ_BLOCK = 1024;
@@ -1811,12 +1812,12 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
         O.gid = (t0 >> 8) + w;
-        if (RES) fj_count_batch<true, false>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        if (RES) fj_count_batch<true, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
         else     fj_count_batch<false, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
-            if (!RES && i < un.count) {
+            if (i < un.count) {
                 // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
                 // this tuple was a different key, so phase 2 must verify its candidates again
                 scnt[i] = (uint8_t)(min(c[k], 127u) | (fp[k] ? 0x80u : 0u));
@@ -1825,7 +1826,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             mine += c[k];
             needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
         }
-        if (!RES) {                                   // group total for the barrier-free emit pass
+        {                                             // group total for the barrier-free emit pass
             uint32_t gt;
             wave_excl_scan_u32(c[0] + c[1] + c[2] + c[3], &gt);
             if (lane == 0) O.table[O.gid * 16u] = gt;
@@ -1866,7 +1867,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         pend = 0xffffffffu;
         __syncthreads();
     }
-    if (emitting && !RES && !unit_needs_index) {      // this unit's emit pass needs no index: defer it
+    if (emitting && !unit_needs_index) {              // this unit's emit pass needs no index: defer it
         pend = u;
         pend_total = total;
         pend_dup = ovf_total != 0;
