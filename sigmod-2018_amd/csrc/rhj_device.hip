@@ -67,6 +67,7 @@ struct Ctx {
     int         ablate = 0;
     int         no_fused = 0;
     int         no_resident = 0;
+    int         wide_row_ids = 0;    // 1: never use 12-byte intermediates (env RHJ_WIDE_ROW_IDS)
     int         cus = 256;           // compute units of the device (one fused workgroup each)
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
@@ -97,6 +98,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);
         if ((e = getenv("RHJ_NO_FUSED"))) g.no_fused = atoi(e);
         if ((e = getenv("RHJ_NO_RESIDENT"))) g.no_resident = atoi(e);
+        if ((e = getenv("RHJ_WIDE_ROW_IDS"))) g.wide_row_ids = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
     }
 } env_defaults;
@@ -132,8 +134,10 @@ int ctx_init()
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     g.ready = true;
     return 0;
 }
@@ -196,7 +200,7 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
 // Stage events: one pass  ST_HIST..ST_SCAN histogram, ST_SCAN..ST_SCATTER scan, ST_SCATTER..ST_PLAN scatter;
 //               two passes ST_HIST..ST_SCAN pass 1, ST_SCAN..ST_SCATTER pass-2 histogram + scan,
 //                          ST_SCATTER..ST_PLAN pass-2 scatter.
-int run_partition(PartState &ps, int bits, int nrel)
+int run_partition(PartState &ps, int bits, int nrel, bool force_wide)
 {
     const uint32_t bins = 1u << bits;
     if (ensure(g.histpsum, (size_t)4 * bins * 8) || ensure(g.passhp, (size_t)4 * 256 * 8)) return -1;
@@ -204,6 +208,8 @@ int run_partition(PartState &ps, int bits, int nrel)
     ps.psum = ps.hist + 2 * bins;
     RelArgs none = RelArgs{};
     for (int i = 0; i < nrel; ++i) ps.r[i].tiles = tiles_for(ps.r[i].n);
+    if (ensure(g.summary, sizeof(PlanSummary))) return -1;
+    HIP_TRY(hipMemsetAsync(&((PlanSummary *)g.summary.p)->wide_row_ids, 0, 8, g.stream));    // wide_row_ids, row_id_overflow
     if (ensure(g.cntR, (size_t)ps.r[0].tiles * 256 * 4)) return -1;
     ps.r[0].cnt = (uint32_t *)g.cntR.p;
     if (nrel > 1) {
@@ -250,8 +256,14 @@ int run_partition(PartState &ps, int bits, int nrel)
         if (ar[i]->tiles > max1) max1 = ar[i]->tiles;
         if (b.tiles > max2) max2 = b.tiles;
     }
+    // 12-byte intermediates when the row ids fit 32 bits: a sample decides on the device, both
+    // instantiations are launched and the one not chosen returns at once (no host round trip)
+    if (ensure(g.summary, sizeof(PlanSummary))) return -1;
+    PlanSummary *dsum = (PlanSummary *)g.summary.p;
     HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    RHJ_LAUNCH(k_local_part, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi);
+    RHJ_LAUNCH(k_rowid_sample, dim3(1), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
+    RHJ_LAUNCH(k_local_part<true>, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
+    RHJ_LAUNCH(k_local_part<false>, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
     HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
@@ -277,8 +289,10 @@ int run_partition(PartState &ps, int bits, int nrel)
     {
         const uint32_t sgrid = (uint32_t)g.cus * 2u;          // the workgroups that are resident together (two per CU)
         const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;     // a multiple of the 8 XCDs
-        RHJ_LAUNCH(k_scatter_runs, dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
-                   lo, hi, search0);
+        RHJ_LAUNCH(k_scatter_runs<true>, dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+                   lo, hi, search0, (const PlanSummary *)dsum);
+        RHJ_LAUNCH(k_scatter_runs<false>, dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+                   lo, hi, search0, (const PlanSummary *)dsum);
     }
     RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
                        ps.psum);
@@ -307,9 +321,11 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
 
 // The whole device-side join.  out == nullptr && use_ctx_out: the pairs land in the
 // context's own buffer (grown after the count pass), returned through *ctx_out.
-int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
-                uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
+int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
+                     uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches,
+                     bool force_wide, bool *overflow)
 {
+    *overflow = false;
     if (ctx_init()) return -1;
     rhj_stats &st = g.stats;
     const float keep_h2d = st.ms_h2d;
@@ -336,7 +352,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         if (ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple))) return -1;
         ps.tmp[0] = (rhj_tuple *)g.tmpR.p; ps.tmp[1] = (rhj_tuple *)g.tmpS.p;
     }
-    if (run_partition(ps, bits, 2)) return -1;
+    if (run_partition(ps, bits, 2, force_wide)) return -1;
 
     // ---- plan
     const uint32_t build_chunk = 4096;
@@ -447,6 +463,7 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
             out_capacity = M;
         }
         if (fused_done) {
+            *overflow = plan.row_id_overflow != 0;
             st.units = plan.units; st.hbm_units = 0; st.max_build = plan.max_build;
             *matches = M;
             st.matches = M;
@@ -495,6 +512,8 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
         return -1;
     HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));                  // sync #2: match count -> output size
+    *overflow = hs->row_id_overflow != 0;
+    if (*overflow) return 0;                                  // the caller runs the join again with wide intermediates
     const uint64_t M = hs->matches;
     *matches = M;
     st.matches = M;
@@ -525,6 +544,19 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     st.ms_offsets = ev_ms(g.ev[ST_OFFSETS], g.ev[ST_PROBE]);
     st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
     st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    return rc;
+}
+
+// The two-pass partition keeps 12-byte tuples between its passes when the row ids fit 32 bits (decided
+// on the device from a sample).  If a wider row id went through anyway, the pairs carry truncated row
+// ids: the join is run again with 16-byte intermediates.
+int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
+                uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
+{
+    bool overflow = false;
+    int rc = join_device_once(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, g.wide_row_ids != 0, &overflow);
+    if (rc >= 0 && overflow)
+        rc = join_device_once(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, true, &overflow);
     return rc;
 }
 
@@ -661,13 +693,18 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
         if (ensure(g.tmpR, (n ? n : 1) * sizeof(rhj_tuple))) return -1;
         ps.tmp[0] = (rhj_tuple *)g.tmpR.p;
     }
-    if (run_partition(ps, bits, 1)) return -1;
-    HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
     uint64_t *hh = (uint64_t *)malloc((size_t)2 * bins * 8);
     if (!hh) return -1;
-    HIP_TRY(hipMemcpyAsync(hh, ps.hist, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(hh + bins, ps.psum, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (run_partition(ps, bits, 1, attempt == 1 || g.wide_row_ids != 0)) { free(hh); return -1; }
+        HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+        PlanSummary *hs = (PlanSummary *)g.pin;
+        HIP_TRY(hipMemcpyAsync(hh, ps.hist, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(hh + bins, ps.psum, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (!hs->row_id_overflow) break;                      // else: a row id above 2^32 - 1 met a 12-byte intermediate
+    }
     for (uint32_t b = 0; b < bins; ++b) {
         if (h_hist) h_hist[b] = hh[b];
         if (h_psum) h_psum[b] = hh[b] ? (int64_t)hh[bins + b] : -1;      // preprocess.c:336-347

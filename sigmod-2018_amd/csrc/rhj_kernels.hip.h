@@ -82,7 +82,8 @@ struct PlanSummary {
     uint64_t max_build;          // largest build side
     uint64_t matches;            // filled by k_offsets / k_fused_total
     uint64_t fused_ok;           // every active bucket's build side <= lds_cap (fused path usable)
-    uint64_t pad;
+    uint32_t wide_row_ids;       // two-pass partition: 1 = the intermediate array keeps 16-byte tuples, 0 = 12-byte
+    uint32_t row_id_overflow;    // a row id above 2^32 - 1 went through a 12-byte intermediate: run again wide
 };
 
 struct JoinArgs {
@@ -380,6 +381,35 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
     }
 }
 
+// Intermediate tuple of the two-pass partition when row ids fit 32 bits: {key, u32 row id}, 12 bytes.
+// Every row id the reference puts into a relation is an index below the relation's size
+// (inter_res.c:202,225), so this is the normal case; the ABI does not promise it, so a sample decides
+// (k_rowid_sample) and pass 1 raises row_id_overflow if a wider row id slips through (the host then
+// runs the join again with 16-byte intermediates).
+struct __attribute__((aligned(4))) Tuple12 { uint32_t klo, khi, rid; };
+
+// first and last 2048 row ids of both relations -> summary->wide_row_ids; clears the overflow word
+__global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, int nrel, int force_wide, PlanSummary *summary)
+{
+    __shared__ uint32_t any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int rel = 0; rel < nrel; ++rel) {
+        const RelArgs &r = rel ? r1 : r0;
+        for (uint32_t j = threadIdx.x; j < 2048; j += 256) {
+            if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32);
+            if (j < r.n) mine |= (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
+        }
+    }
+    if (mine) atomicOr(&any, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        summary->wide_row_ids = (force_wide || any) ? 1u : 0u;
+        summary->row_id_overflow = 0;
+    }
+}
+
 // ---- two-pass partition in run form (radix bits 9..15) ------------------------------------------
 // Pass 1 needs no histogram and no global offsets: every 4096-tuple tile is stably partitioned on
 // the LOW digit inside LDS and written back to the same place in the intermediate array, fully
@@ -391,8 +421,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
 // scatter over these tiles give the final array.  Compared with two offset-driven passes this drops
 // the first pass' histogram read of both relations and turns the first pass' scattered run writes
 // into streaming writes; pass 2 reads 1 KiB runs instead of a contiguous tile.
-__global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits)
+template <bool T12>
+__global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
+                                                         PlanSummary *summary)
 {
+    if ((summary->wide_row_ids == 0) != T12) return;      // the other instantiation's launch moves the data
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
@@ -466,16 +499,20 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     __syncthreads();
 
     uint4 *out = reinterpret_cast<uint4 *>(r.out) + beg;
+    Tuple12 *out12 = reinterpret_cast<Tuple12 *>(r.out) + beg;
     uint8_t *dg = r.dig_out + beg;
+    bool wide = false;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t p = k * PT_BLOCK + threadIdx.x;
         if (p < count) {
             const uint4 v = stage[p];
-            out[p] = v;
+            if (T12) { out12[p] = Tuple12{v.x, v.y, v.z}; wide = wide || v.w != 0; }
+            else out[p] = v;
             dg[p] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
         }
     }
+    if (T12 && __ballot(wide) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->row_id_overflow, 1u);
 }
 
 // pass-2 tile -> its runs: thread i < group describes run i (two coalesced reads of the transposed table)
@@ -555,8 +592,11 @@ __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, 
     }
 }
 
-__global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0)
+template <bool T12>
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
+                                                           const PlanSummary *summary)
 {
+    if ((summary->wide_row_ids == 0) != T12) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
@@ -633,7 +673,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
                         if (runoff[pos + s2] <= e) pos += s2;
                 }
             }
-            if (ok[k]) t[k] = in[rbase[pos] + e];
+            if (ok[k]) {
+                if (T12) { const Tuple12 x = reinterpret_cast<const Tuple12 *>(r.in)[rbase[pos] + e]; t[k] = make_uint4(x.klo, x.khi, x.rid, 0u); }
+                else t[k] = in[rbase[pos] + e];
+            }
         }
         __syncthreads();
 
@@ -797,7 +840,8 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
         PlanSummary s;
         s.units = tot_u; s.build_units = tot_b; s.hbm_slots = tot_s64; s.lds_buckets = tot_l;
         s.tab32_slots = tot_s32; s.max_lds_slots = red[1]; s.max_build = red[0]; s.matches = 0;
-        s.fused_ok = tot_b == 0; s.pad = 0;
+        s.fused_ok = tot_b == 0;
+        s.wide_row_ids = a.summary->wide_row_ids; s.row_id_overflow = a.summary->row_id_overflow;     // the partition's words
         *a.summary = s;
     }
 }

@@ -71,6 +71,35 @@ def test_arbitrary_row_ids(rhj, golden, oracle):
     assert_digest(oracle, rhj.RadixHashJoin(R, S), rec, "arbitrary_row_ids host")
 
 
+@pytest.mark.parametrize("where", ["none", "ends", "middle_only", "one_in_S"])
+@pytest.mark.parametrize("bits", [9, 12, 14])
+def test_row_ids_wider_than_32_bits_in_the_two_pass_partition(rhj, oracle, where, bits):
+    """The two-pass partition keeps 12-byte tuples between its passes when a sample of the row ids fits
+    32 bits; wide row ids the sample does not see (middle of the array) must be caught by pass 1 and the
+    join run again with 16-byte intermediates.  Same for the partition entry point."""
+    nR, nS = 60_000, 90_000
+    R = oracle.generate(nR, 0, 0, 0.0, 71)
+    S = oracle.generate(nS, 1, nR, 0.0, 72)
+    wide = np.uint64(1) << np.uint64(40)
+    if where == "ends":
+        R["row_id"][:10] += wide
+        S["row_id"][-3:] += wide
+    elif where == "middle_only":
+        R["row_id"][nR // 2: nR // 2 + 5] += wide
+        S["row_id"][nS // 3] += wide
+    elif where == "one_in_S":
+        S["row_id"][nS // 2] = np.uint64(0xFFFFFFFF00000001)
+    set_path(rhj, "fused")
+    rhj.set_bits(bits)
+    want = oracle.join(R, S, bits)
+    got = dev_join(rhj, R, S)
+    assert len(got) == len(want) and (got == want).all()
+    wpart, whist, wpsum = oracle.partition(S, bits)
+    out, hist, psum = rhj.partition_device(rhj.to_device(S), bits)
+    part = out.cpu().numpy().view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
+    assert (part == wpart).all() and (hist == whist).all() and (psum == wpsum).all()
+
+
 def test_last_bucket_skew(rhj, golden, oracle):
     k = golden.edges["last_bucket_skew"]
     vals = np.array(k["values_R"], dtype=np.uint64)
