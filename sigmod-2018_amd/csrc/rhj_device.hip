@@ -134,8 +134,7 @@ int ctx_init()
     HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     g.ready = true;
@@ -256,14 +255,14 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide)
         if (ar[i]->tiles > max1) max1 = ar[i]->tiles;
         if (b.tiles > max2) max2 = b.tiles;
     }
-    // 12-byte intermediates when the row ids fit 32 bits: a sample decides on the device, both
-    // instantiations are launched and the one not chosen returns at once (no host round trip)
+    // 12-byte intermediates when the row ids fit 32 bits: a sample decides on the device and the pass
+    // kernels read the decision there (no host round trip; pass 2 is compiled once per format and the
+    // instantiation not chosen returns at once)
     if (ensure(g.summary, sizeof(PlanSummary))) return -1;
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
     HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-    RHJ_LAUNCH(k_rowid_sample, dim3(1), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
-    RHJ_LAUNCH(k_local_part<true>, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
-    RHJ_LAUNCH(k_local_part<false>, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
+    RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
+    RHJ_LAUNCH(k_local_part, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
     HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile

@@ -388,26 +388,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
 // runs the join again with 16-byte intermediates).
 struct __attribute__((aligned(4))) Tuple12 { uint32_t klo, khi, rid; };
 
-// first and last 2048 row ids of both relations -> summary->wide_row_ids; clears the overflow word
+// first and last 2048 row ids of both relations -> summary->wide_row_ids (the host cleared both words)
 __global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, int nrel, int force_wide, PlanSummary *summary)
 {
-    __shared__ uint32_t any;
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    uint32_t mine = 0;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;       // 8 workgroups: 2048 positions from each end
+    uint32_t mine = force_wide ? 1u : 0u;
     for (int rel = 0; rel < nrel; ++rel) {
         const RelArgs &r = rel ? r1 : r0;
-        for (uint32_t j = threadIdx.x; j < 2048; j += 256) {
-            if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32);
-            if (j < r.n) mine |= (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
-        }
+        if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32) | (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
     }
-    if (mine) atomicOr(&any, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        summary->wide_row_ids = (force_wide || any) ? 1u : 0u;
-        summary->row_id_overflow = 0;
-    }
+    if (__ballot(mine != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->wide_row_ids, 1u);
 }
 
 // ---- two-pass partition in run form (radix bits 9..15) ------------------------------------------
@@ -421,11 +411,10 @@ __global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, in
 // scatter over these tiles give the final array.  Compared with two offset-driven passes this drops
 // the first pass' histogram read of both relations and turns the first pass' scattered run writes
 // into streaming writes; pass 2 reads 1 KiB runs instead of a contiguous tile.
-template <bool T12>
 __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
                                                          PlanSummary *summary)
 {
-    if ((summary->wide_row_ids == 0) != T12) return;      // the other instantiation's launch moves the data
+    const bool T12 = summary->wide_row_ids == 0;          // 12-byte intermediates (workgroup-uniform)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
@@ -592,11 +581,11 @@ __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, 
     }
 }
 
-template <bool T12>
+template <bool T12>                                   // (a run-time switch here cost 30 %: compiled apart, both launched)
 __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
                                                            const PlanSummary *summary)
 {
-    if ((summary->wide_row_ids == 0) != T12) return;
+    if ((summary->wide_row_ids == 0) != T12) return;      // the other instantiation's launch moves the data
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
