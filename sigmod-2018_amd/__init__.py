@@ -91,7 +91,7 @@ def build():
 
 
 def load_library(path=None):
-    LIB_PATH = path or globals()["LIB_PATH"]
+    LIB_PATH = path or os.environ.get("RHJ_LIB") or globals()["LIB_PATH"]      # RHJ_LIB: e.g. the diagnostics build, `make instr`
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("librhj.so is not built (run `make -C sigmod-2018_amd` or __graft_entry__.build()); "
                            "this package has no CPU fallback")

@@ -1761,6 +1761,15 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
 // not need its index any more (no probe tuple with two or more matches: the foreign-key case) is
 // DEFERRED behind the next unit's build + phase 1: by then its output base has long been published,
 // so such units never wait on the chain (the wait was 18 % of a unit in the in-kernel stamps).
+// Diagnostics of the fused kernel (in-kernel phase stamps, RHJ_STAMPS; parts switched off, RHJ_ABLATE)
+// are compiled in only with -DRHJ_INSTRUMENT (tools/): the production kernel carries no trace of them.
+#ifdef RHJ_INSTRUMENT
+#define FJ_DBG (f.dbg)
+#define FJ_ABLATE (a.ablate)
+#else
+#define FJ_DBG ((uint64_t *)nullptr)
+#define FJ_ABLATE 0u
+#endif
 template <bool MAYRES>
 __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
 {
@@ -1775,7 +1784,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     unsigned long long *st = (unsigned long long *)f.status;
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const uint64_t cap = a.out_capacity;
-    const bool emitting = out != nullptr && a.ablate != 3;
+    const bool emitting = out != nullptr && FJ_ABLATE != 3;
     uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
     uint64_t pend_total = 0;
     bool pend_dup = false;
@@ -1823,12 +1832,12 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     O.counter = &sh_ovf;
     O.gid = 0;
 
-    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
     if (RES) fj_build<true>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
     else     fj_build<false>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
-    if (a.ablate == 1) continue;                      // timing experiment: build only
-    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (FJ_ABLATE == 1) continue;                      // timing experiment: build only
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
     uint32_t mine = 0;
@@ -1867,7 +1876,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     }
 
     // ---- unit total -> chained scan
-    if (f.dbg && lane == 0) { if (w == 0) f.dbg[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
+    if (FJ_DBG && lane == 0) { if (w == 0) FJ_DBG[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
     {
         uint32_t tot;
         wave_excl_scan_u32(mine, &tot);
@@ -1906,7 +1915,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         pend_dup = ovf_total != 0;
         pend_ovf = O.buf;
         pend_table = O.table;
-        if (f.dbg && threadIdx.x == 0) { f.dbg[(size_t)u * 8 + 3] = f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
+        if (FJ_DBG && threadIdx.x == 0) { FJ_DBG[(size_t)u * 8 + 3] = FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
         continue;
     }
 
@@ -1919,7 +1928,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     }
     __syncthreads();
 
-    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     // ---- phase 2: emit (general form: duplicates and tag collisions walk the index again)
     uint64_t run = sh_base;
     if (!emitting) continue;
@@ -2033,7 +2042,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
     }
-    if (f.dbg && threadIdx.x == 0) f.dbg[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     }   // ticket loop
 
     if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup

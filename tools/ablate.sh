@@ -1,5 +1,7 @@
 #!/bin/bash
 # timing experiments: join-phase time with parts removed (results are wrong by design)
+# needs the diagnostics build: make -C sigmod-2018_amd instr
+export RHJ_LIB=${RHJ_LIB:-sigmod-2018_amd/librhj_instr.so}
 for m in 0 1 2 3; do
   RHJ_ABLATE=$m python3 - <<PY
 import importlib, ctypes as C, torch, sys

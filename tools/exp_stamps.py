@@ -3,6 +3,8 @@ import numpy as np
 sys.path.insert(0, ".")
 import bench
 os.environ["RHJ_STAMPS"] = "1"
+# needs the diagnostics build: make -C sigmod-2018_amd instr
+os.environ.setdefault("RHJ_LIB", os.path.join("sigmod-2018_amd", "librhj_instr.so"))
 mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
 nR, nS = [int(x) for x in sys.argv[1:3]]
 w = dict(nR=nR, nS=nS, bits=12, dist="uniform")
@@ -23,26 +25,8 @@ t0 = t[:, 0].min()
 us = lambda a: a / 100.0
 print("fused %.3f ms, units %d" % (st["ms_probe"], units))
 print("span (first start -> last end): %.1f us" % us(t[:, 4].max() - t0))
-for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("phase1(w15 end)-(w0 end)", 2, 5), ("chain+barrier", 2, 3), ("phase2", 3, 4), ("unit total", 0, 4)):
+for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("chain+barrier", 2, 3), ("phase2", 3, 4), ("unit total", 0, 4)):
     d = us(t[:, b] - t[:, a])
     print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 starts = np.sort(us(t[:, 0] - t0))
 print("start times of units 0,255,256,511,1024,4095: ", [round(float(starts[i]), 1) for i in (0, 255, 256, 511, 1024, units - 1)])
-
-for name, col, hi in (("p1 load", 6, True), ("p1 walk", 6, False), ("p1 gather", 7, True), ("p1 stash", 7, False)):
-    v = (buf[:, col] >> np.uint64(32)) if hi else (buf[:, col] & np.uint64(0xffffffff))
-    d = us(v.astype(np.int64))
-    print("%-28s mean %.1f  p50 %.1f  max %.1f us (wave 1, drained at every stamp)" % (name, d.mean(), np.median(d), d.max()))
-
-flags = buf[:, 6] & np.uint64(0xff)
-print("flag histogram (1 needs_index, 2 RES, 4 emitting):", np.unique(flags, return_counts=True))
-print("unit totals:", (buf[:8, 6] >> np.uint64(8)))
-
-gen = (flags & np.uint64(1)) != 0
-for name, v in (("p2 load+stash", buf[:, 7] >> np.uint64(32)), ("p2 scan+barriers", buf[:, 7] & np.uint64(0xffffffff)), ("p2 stores+walk", buf[:, 5])):
-    d = us(v.astype(np.int64))[gen]
-    print("general phase 2, wave 1: %-18s mean %.1f p50 %.1f max %.1f us" % (name, d.mean(), np.median(d), d.max()))
-for sel, nm in ((gen, "dup units"), (~gen, "fk units")):
-    for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("2->3", 2, 3), ("phase2", 3, 4)):
-        d = us(t[:, b] - t[:, a])[sel]
-        print("%s %-12s mean %.1f p50 %.1f" % (nm, name, d.mean(), np.median(d)))
