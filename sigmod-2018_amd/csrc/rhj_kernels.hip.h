@@ -1948,20 +1948,16 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 okk[h][k] = i < un.count;
                 fpt[h][k] = false;
                 q[h][k] = okk[h][k] ? pr4[i] : make_uint4(0, 0, 0, 0);
-                if (!RES) {
-                    const uint32_t sb = okk[h][k] ? scnt[i] : 0;
-                    c[h][k] = sb & 0x7fu;
-                    fpt[h][k] = (sb & 0x80u) != 0;
-                    const uint2 fr = okk[h][k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
-                    flo[h][k] = fr.x; fhi[h][k] = fr.y;
-                }
+                const uint32_t sb = okk[h][k] ? scnt[i] : 0;
+                c[h][k] = sb & 0x7fu;
+                fpt[h][k] = (sb & 0x80u) != 0;
+                const uint2 fr = okk[h][k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
+                flo[h][k] = fr.x; fhi[h][k] = fr.y;
             }
         }
 #pragma unroll
         for (int h = 0; h < FJ_H; ++h) {
-            if (RES) {
-                fj_count_batch<true, false>(X, G, ltup, q[h], okk[h], c[h], flo[h], fhi[h], fpt[h], O);   // LDS only: cheaper than a stash round trip
-            } else {
+            {
                 // saturated counts: recount from the index (also yields the exact number to emit)
 #pragma unroll
                 for (int k = 0; k < FJ_V; ++k) {
@@ -1971,7 +1967,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                         uint32_t n = 0;
                         for (uint32_t at = X.H(sl + 1u), end = X.H(sl + 2u); at < end; ++at) {
                             const uint32_t nd = X.ent[at];
-                            if ((nd >> 16) == t) { const uint4 v = G.load(nd & 0xffffu); n += (v.x == q[h][k].x && v.y == q[h][k].y); }
+                            if ((nd >> 16) == t) { const uint4 v = RES ? ltup[nd & 0xffffu] : G.load(nd & 0xffffu); n += (v.x == q[h][k].x && v.y == q[h][k].y); }
                         }
                         c[h][k] = n;
                     }
