@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -126,7 +127,15 @@ std::unordered_set<const void *> g_rel, g_res, g_inter;
 
 // RHJ_TRACE=1: one line per call on stderr (which operator, which relations, how many rows)
 bool tracing() { static const bool on = getenv("RHJ_TRACE") != nullptr; return on; }
-#define TRACE(...) do { if (tracing()) { fprintf(stderr, "rhj-trace: " __VA_ARGS__); fputc('\n', stderr); } } while (0)
+double trace_ms()
+{
+    static struct timespec t0 = {0, 0};
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = t;
+    return (t.tv_sec - t0.tv_sec) * 1e3 + (t.tv_nsec - t0.tv_nsec) * 1e-6;
+}
+#define TRACE(...) do { if (tracing()) { fprintf(stderr, "rhj-trace %9.2f ms: ", trace_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 void trace_nodes(const rhj_inter_res *h)
 {
     if (!tracing()) return;
@@ -286,6 +295,7 @@ rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS)
 {
     rhj_result_tuple *out = nullptr;
     uint64_t m = 0;
+    TRACE("RadixHashJoin %lu x %lu", (unsigned long)relR->num_tuples, (unsigned long)relS->num_tuples);
     if (rhj_dev_join(relR->tuples, relR->num_tuples, relS->tuples, relS->num_tuples, &out, &m) < 0) die("RadixHashJoin");
     if (m == 0) {
         if (rhj_host_null_on_empty()) return nullptr;          // THREADS 1 behaviour
@@ -313,6 +323,7 @@ rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, 
     const uint64_t value = (uint64_t)(int64_t)filter_p->value;   // int -> u64, filter.c:116
     if (n == 0) return nullptr;
     uint64_t *ids = alloc_ids(n), hits = 0;
+    TRACE("Filter over %lu rows", (unsigned long)n);
     if (rhj_filter_device(col, sel, n, op, value, ids, &hits)) die("Filter");
     if (hits == 0) { rhj_dev_free(ids); return nullptr; }        // filter.c:94,189
     return make_result(ids, hits);
@@ -551,6 +562,7 @@ void CalculateQueryResults(rhj_inter_res *inter, rhj_relation_map *map, rhj_batc
 
 void PrintNullResults(rhj_batch_listnode *query)                                    // inter_res.c:341-350
 {
+    TRACE("PrintNullResults");
     for (int i = 0; i < query->views->num_of_elements; i++) {
         printf("NULL");
         if (i != query->views->num_of_elements - 1) printf(" ");
@@ -697,6 +709,7 @@ int rhj_column_stats_device(const uint64_t *d_col, uint64_t n, uint64_t *l, uint
 int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)           // relation_map.c:13-88
 {
     int i = 0;
+    TRACE("InitRelationMap begins");
     while (head != nullptr) {
         struct stat sb;
         if ((head->fd = open(head->filename, O_RDONLY)) == -1) return 1;
@@ -722,6 +735,7 @@ int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)     
         }
         head = head->next;
         i++;
+        TRACE("InitRelationMap: relation %d loaded", i - 1);
     }
     return 0;
 }
