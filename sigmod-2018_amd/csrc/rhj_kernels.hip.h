@@ -167,6 +167,25 @@ constexpr int PT_WAVES = PT_BLOCK / WAVE;
 constexpr int PT_MAX_BITS = 8;                    // digit bits per pass
 constexpr uint32_t PT_MAX_GROUP = 256;            // pass-1 tiles per pass-2 tile (run form), at most
 
+// The lanes of a wave that hold the same digit as this lane (match-any over `bits` ballots).
+// pb is all ones when the lane's bit is set: peers keeps m where the bit is set and ~m where it is
+// clear, i.e. peers &= ~(m ^ pb), one three-input bit operation per half and bit.
+__device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok, int bits)
+{
+    const uint64_t valid = __ballot(ok);
+    uint32_t plo = (uint32_t)valid, phi = (uint32_t)(valid >> 32);
+#pragma unroll
+    for (int b = 0; b < PT_MAX_BITS; ++b) {
+        if (b < bits) {                               // wave-uniform
+            const uint32_t pb = ok ? 0u - ((d >> b) & 1u) : 0u;
+            const uint64_t m = __ballot(pb != 0);
+            plo &= ~((uint32_t)m ^ pb);
+            phi &= ~((uint32_t)(m >> 32) ^ pb);
+        }
+    }
+    return ((uint64_t)phi << 32) | plo;
+}
+
 // Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
 __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits)
 {
@@ -328,11 +347,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch)
         const uint32_t d = (uint32_t)(key >> shift) & mask;
         dig[k] = d;
-        uint64_t peers = __ballot(ok[k]);
-        for (int b = 0; b < bits; ++b) {
-            const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
+        const uint64_t peers = digit_peers(d, ok[k], bits);
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
         uint32_t old = 0;
         if (ok[k] && rank == 0) {                       // lowest lane of each digit group
@@ -450,8 +465,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
         dig[k] = d;
-        uint64_t peers = __ballot(ok[k]);
-        for (int b = 0; b < bits; ++b) {
+        uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
+        for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
             const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -676,11 +691,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
             const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;
             const uint32_t d = (uint32_t)(key >> shift) & mask;
             dig[k] = d;
-            uint64_t peers = __ballot(ok[k]);
-            for (int b = 0; b < bits; ++b) {
-                const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
-                peers &= ((d >> b) & 1u) ? m : ~m;
-            }
+            const uint64_t peers = digit_peers(d, ok[k], bits);
             const uint32_t rank = (uint32_t)__popcll(peers & lt);
             uint32_t old = 0;
             if (ok[k] && rank == 0) {
