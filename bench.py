@@ -26,6 +26,8 @@ import time
 
 import numpy as np
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -38,6 +40,9 @@ WORKLOADS = {
     "c4b15": dict(nR=100_000_000, nS=1_000_000_000, bits=15, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 15 radix bits"),
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
     "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
+    # BASELINE configs[4]: the SIGMOD'18 `small` workload through the reference's own driver and query executor
+    # linked against librhj.so (device-resident configuration); the 50 queries are dealt round-robin to the ranks
+    "small": dict(name="SIGMOD'18 small workload (14 relations, 50 queries), reference driver + librhj.so, queries sharded over the ranks"),
 }
 
 
@@ -160,6 +165,90 @@ def cpu_baseline(w):
                     "the serial path is the reference's faster and correct mode"}
 
 
+def run_small(args, world, rank, local, dist):
+    """One engine process per rank and step (oracle/_ref/radixhash_rhj_resident: handler.c, query.c, stats.c,
+    best_tree.c, relation_list.c of the reference + librhj.so) on the rank's share of the queries; rank 0
+    merges the answers in query order and checks them against small.result (tests/golden)."""
+    import subprocess, tempfile
+    import numpy as np
+    for p in (os.path.join(HERE, "tests"), os.path.join(HERE, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import helpers
+    g = helpers.Golden()
+    exe = os.path.join(HERE, "oracle", "_ref", "radixhash_rhj_resident")
+    ref = os.path.join(HERE, "oracle", "_ref", "radixhash_t4")
+    if not os.path.exists(exe):
+        raise RuntimeError("oracle/_ref/radixhash_rhj_resident is not built (needs /root/reference at build time)")
+    tmp = tempfile.mkdtemp()
+    names = []
+    for i in range(14):
+        cols = g.small_relations["r%d" % i].astype("<u8")
+        with open(os.path.join(tmp, "r%d" % i), "wb") as f:
+            np.array([cols.shape[1], cols.shape[0]], dtype="<u8").tofile(f)
+            cols.tofile(f)
+        names.append("r%d" % i)
+    queries = [l for l in g.small["work_lines"] if "|" in l]
+    mine = [i for i in range(len(queries)) if i % world == rank]
+    head = "\n".join(names) + "\nDone\n"
+    stdin = (head + "\n".join(queries[i] for i in mine) + "\nF\n").encode()
+    env = dict(os.environ, RHJ_DEVICE=str(local))
+
+    def run(path, data):
+        r = subprocess.run([path], input=data, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr.decode()[-1000:])
+        return r.stdout.decode().splitlines()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        run(exe, stdin)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lines = run(exe, stdin)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, lines))
+    else:
+        gathered = [(mine, lines)]
+    if rank == 0:
+        answers = [None] * len(queries)
+        for idx, ls in gathered:
+            assert len(idx) == len(ls), "a rank printed %d lines for %d queries" % (len(ls), len(idx))
+            for i, l in zip(idx, ls):
+                answers[i] = l
+        assert answers == g.small["result_lines"], "the merged answers differ from small.result"
+        res = {"metric": "queries/s on the SIGMOD'18 small workload (whole engine processes, start-up included)",
+               "value": len(queries) * args.steps / elapsed, "unit": "queries/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "SIGMOD'18 small (fixture)",
+               "config": {"workload": WORKLOADS["small"]["name"], "id": "small", "queries": len(queries),
+                          "parallelism": "queries round-robin over %d rank(s), no collective on the data path" % world,
+                          "answers": "identical to small.result"},
+               "roofline": None}
+        if world == 1 and not args.no_cpu_baseline and os.path.exists(ref):
+            all_stdin = (head + "\n".join(queries) + "\nF\n").encode()
+            t1 = time.perf_counter()
+            ref_lines = run(ref, all_stdin)
+            dt = time.perf_counter() - t1
+            res["cpu_baseline"] = {"value": len(queries) / dt, "unit": "queries/s", "cores": 4, "kind": "reference",
+                                   "sample": "the reference engine as shipped (THREADS 4), all 50 queries, %.3f s; answers %s" % (
+                                       dt, "identical" if ref_lines == g.small["result_lines"] else "DIFFER")}
+        print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +277,11 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
+    if args.workload == "small":
+        run_small(args, world, rank, local, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     w = WORKLOADS[args.workload]
     mod = importlib.import_module("sigmod-2018_amd")
     rhj = mod.RHJ(device=local)

@@ -45,3 +45,17 @@ def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode, engine
     assert len(got) == len(want) == 50
     bad = [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w]
     assert not bad, bad[:5]
+
+
+def test_bench_small_workload_mode_checks_and_reports(tmp_path):
+    """bench.py --workload small (BASELINE configs[4], query-sharded): the run itself asserts that the merged
+    answers equal small.result; here one rank, one step."""
+    import json
+    import sys
+    if not os.path.exists(ENGINES["radixhash_rhj_resident"]):
+        pytest.skip("oracle/_ref/radixhash_rhj_resident not built")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["config"]["answers"] == "identical to small.result" and line["config"]["queries"] == 50 and line["value"] > 0
