@@ -270,3 +270,16 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert res.returncode == 0 and b"ok" in res.stdout, res.stderr.decode()[-1500:]
+
+
+def test_full_size_properties_c4(rhj):
+    """BASELINE config 4 (100M x 1B Zipf(0.9) FK, 14 radix bits: LDS-resident units, skewed buckets split
+    into many units) at full size through the size-independent properties."""
+    import bench
+    w = bench.WORKLOADS["c4"]
+    rhj.set_bits(w["bits"])
+    R, S = bench.make_relations(w, rhj.dev, 7)
+    t, m = rhj.join_device(R, S, capacity=w["nS"])
+    bench.check_properties(R, S, t, m, w)
+    del R, S, t
+    rhj.torch.cuda.empty_cache()
