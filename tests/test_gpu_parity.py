@@ -283,3 +283,31 @@ def test_full_size_properties_c4(rhj):
     bench.check_properties(R, S, t, m, w)
     del R, S, t
     rhj.torch.cuda.empty_cache()
+
+
+def test_above_2_31_tuples(rhj):
+    """Maximum sizes: a probe side above 2^31 tuples (the reference's own limit is 2^31 - 1, SURVEY.md
+    finding 9; this library's is 2^32 - 1) through the size-independent properties, and the refusal at 2^32."""
+    import bench
+    torch = rhj.torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~170 GB of device memory")
+    w = dict(nR=1_000_000, nS=(1 << 31) + (1 << 22) + 12345, bits=12, dist="uniform")
+    rhj.set_bits(w["bits"])
+    R, S = bench.make_relations(w, rhj.dev, 11)
+    t, m = rhj.join_device(R, S, capacity=w["nS"])
+    bench.check_properties(R, S, t, m, w)
+    # the pairs at the far end of the list, beyond 2^31
+    tail = t[m - 4096:m]
+    assert bool((R[tail[:, 0], 0] == S[tail[:, 1], 0]).all())
+    assert bool(((S[tail[:, 1], 0] & 4095) == 4095).all())
+    del t, tail
+    torch.cuda.empty_cache()
+    import ctypes as C
+    mm = C.c_uint64(0)
+    rc = rhj.lib.rhj_join_device(R.data_ptr(), 1 << 32, S.data_ptr(), 16, None, 0, C.byref(mm))
+    assert rc == -2
+    del R, S
+    rhj.lib.rhj_release()
+    torch.cuda.empty_cache()
