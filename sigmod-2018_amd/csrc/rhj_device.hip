@@ -129,10 +129,12 @@ int ctx_init()
     HIP_TRY(hipHostMalloc(&g.pin, 4096, hipHostMallocDefault));
     // dynamic LDS above 64 KiB has to be requested per kernel
     HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_join_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
+    {
+        const void *fused[4] = {(const void *)k_join_fused<false, false>, (const void *)k_join_fused<false, true>,
+                                (const void *)k_join_fused<true, false>, (const void *)k_join_fused<true, true>};
+        for (const void *k : fused)
+            HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
+    }
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
@@ -215,8 +217,11 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide)
         if (ensure(g.cntS, (size_t)ps.r[1].tiles * 256 * 4)) return -1;
         ps.r[1].cnt = (uint32_t *)g.cntS.p;
     }
-    if (bits <= PT_MAX_BITS)
+    if (bits <= PT_MAX_BITS) {
+        // one pass: no 12-byte intermediates and nothing that checks the row ids, so everything downstream stays wide
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&((PlanSummary *)g.summary.p)->wide_row_ids, 1, 1, g.stream));
         return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, bits, ps.hist, ps.psum);
+    }
 
     // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
     const int lo = bits / 2, hi = bits - lo;
@@ -442,10 +447,15 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             // workgroups are persistent (ticket loop) and the LDS request leaves room for one per CU
             const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
             // the resident variant only when an average bucket could fit beside the index (~7.4 K tuples)
-            if (nmin / bins <= 7000 && !g.no_resident)
-                RHJ_LAUNCH(k_join_fused<true>, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-            else
-                RHJ_LAUNCH(k_join_fused<false>, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            // Both stash widths are launched; the one that does not match the partition's row-id decision
+            // (summary->wide_row_ids, known only on the device) returns at once.
+            if (nmin / bins <= 7000 && !g.no_resident) {
+                RHJ_LAUNCH((k_join_fused<true, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            } else {
+                RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            }
             RHJ_LAUNCH(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
                                (const PlanSummary *)g.summary.p, unit_bound, &((PlanSummary *)g.summary.p)->matches);
             HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));

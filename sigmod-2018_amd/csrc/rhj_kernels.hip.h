@@ -1660,10 +1660,23 @@ __device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t
     return excl;
 }
 
+// The first-match stash holds build row ids: 8 bytes each, or 4 (N32) when the partition found every row id
+// below 2^32 (summary->wide_row_ids == 0; pass 1 checks every tuple and the host runs again wide otherwise).
+template <bool N32> __device__ __forceinline__ void fj_stash_put(void *srow, uint32_t i, uint32_t lo, uint32_t hi)
+{
+    if (N32) reinterpret_cast<uint32_t *>(srow)[i] = lo;
+    else     reinterpret_cast<uint2 *>(srow)[i] = make_uint2(lo, hi);
+}
+template <bool N32> __device__ __forceinline__ uint2 fj_stash_get(const void *srow, uint32_t i)
+{
+    if (N32) return make_uint2(reinterpret_cast<const uint32_t *>(srow)[i], 0u);
+    return reinterpret_cast<const uint2 *>(srow)[i];
+}
+
 // Deferred emit pass of a gather-path unit: pure streaming of the probe row ids, the stash and (DUP)
 // the overflow stash, 8 tuples per lane; the index is not needed.  DUP = false: every probe tuple has
 // zero or one match (the foreign-key case), offsets come from ballots.
-template <bool DUP>
+template <bool DUP, bool N32>
 __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum,
                                                const uint64_t *ovf, uint32_t *table)
 {
@@ -1676,7 +1689,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
     const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
     const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
-    const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
+    const void *srow = reinterpret_cast<const char *>(f.stash_row) + ((flip ? f.nR : 0) + ppos) * (N32 ? 4u : 8u);
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const uint64_t cap = a.out_capacity;
     const uint64_t lt = lanemask_lt();
@@ -1706,7 +1719,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
             const uint32_t i = g * 256u + k * WAVE + lane;
             const bool ok = i < un.count;
             c[k] = ok ? (scnt[i] & 0x7fu) : 0;
-            first[k] = ok ? srow[i] : make_uint2(0, 0);
+            first[k] = ok ? fj_stash_get<N32>(srow, i) : make_uint2(0, 0);
             prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
         }
         // the group's table row: lane 0 its start in the unit's output, lane j the run start of ordinal j
@@ -1784,7 +1797,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
 #define FJ_DBG ((uint64_t *)nullptr)
 #define FJ_ABLATE 0u
 #endif
-template <bool MAYRES>
+template <bool MAYRES, bool N32>
 __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
@@ -1799,6 +1812,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const uint64_t cap = a.out_capacity;
     const bool emitting = out != nullptr && FJ_ABLATE != 3;
+    if ((a.summary->wide_row_ids == 0) != N32) return;                 // the other instantiation's launch does the join
     uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
     uint64_t pend_total = 0;
     bool pend_dup = false;
@@ -1836,7 +1850,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     X.hs = hs0;
     X.dirw = X.ent + bcp + 8u;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
-    uint64_t *srow = f.stash_row + (flip ? f.nR : 0) + ppos;
+    void *srow = reinterpret_cast<char *>(f.stash_row) + ((flip ? f.nR : 0) + ppos) * (N32 ? 4u : 8u);
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
     FjGather G;
     G.init(bd, bc);
@@ -1877,7 +1891,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
                 // this tuple was a different key, so phase 2 must verify its candidates again
                 scnt[i] = (uint8_t)(min(c[k], 127u) | (fp[k] ? 0x80u : 0u));
-                reinterpret_cast<uint2 *>(srow)[i] = make_uint2(flo[k], fhi[k]);
+                fj_stash_put<N32>(srow, i, flo[k], fhi[k]);
             }
             mine += c[k];
             needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
@@ -1918,8 +1932,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         __syncthreads();
-        if (pend_dup) fj_emit_stream<true>(f, pend, sh_base, wsum, pend_ovf, pend_table);
-        else          fj_emit_stream<false>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
         pend = 0xffffffffu;
         __syncthreads();
     }
@@ -1965,7 +1979,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 const uint32_t sb = okk[h][k] ? scnt[i] : 0;
                 c[h][k] = sb & 0x7fu;
                 fpt[h][k] = (sb & 0x80u) != 0;
-                const uint2 fr = okk[h][k] ? reinterpret_cast<const uint2 *>(srow)[i] : make_uint2(0, 0);
+                const uint2 fr = okk[h][k] ? fj_stash_get<N32>(srow, i) : make_uint2(0, 0);
                 flo[h][k] = fr.x; fhi[h][k] = fr.y;
             }
         }
@@ -2065,8 +2079,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         __syncthreads();
-        if (pend_dup) fj_emit_stream<true>(f, pend, sh_base, wsum, pend_ovf, pend_table);
-        else          fj_emit_stream<false>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
     }
 }
 
