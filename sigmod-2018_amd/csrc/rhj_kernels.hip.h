@@ -1660,17 +1660,13 @@ __device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t
     return excl;
 }
 
-// The first-match stash holds build row ids: 8 bytes each, or 4 (N32) when the partition found every row id
-// below 2^32 (summary->wide_row_ids == 0; pass 1 checks every tuple and the host runs again wide otherwise).
-template <bool N32> __device__ __forceinline__ void fj_stash_put(void *srow, uint32_t i, uint32_t lo, uint32_t hi)
+// The first-match stash is 8 bytes per probe tuple: the build row id — or, when the partition found every row
+// id below 2^32 (N32: summary->wide_row_ids == 0; pass 1 checks every tuple and the host runs again wide
+// otherwise), the low words of the build AND the probe row id, so that the deferred emit pass does not read
+// the probe tuples again.
+template <bool N32> __device__ __forceinline__ void fj_stash_put(uint2 *srow, uint32_t i, uint32_t lo, uint32_t hi, uint32_t probe_lo)
 {
-    if (N32) reinterpret_cast<uint32_t *>(srow)[i] = lo;
-    else     reinterpret_cast<uint2 *>(srow)[i] = make_uint2(lo, hi);
-}
-template <bool N32> __device__ __forceinline__ uint2 fj_stash_get(const void *srow, uint32_t i)
-{
-    if (N32) return make_uint2(reinterpret_cast<const uint32_t *>(srow)[i], 0u);
-    return reinterpret_cast<const uint2 *>(srow)[i];
+    srow[i] = N32 ? make_uint2(lo, probe_lo) : make_uint2(lo, hi);
 }
 
 // Deferred emit pass of a gather-path unit: pure streaming of the probe row ids, the stash and (DUP)
@@ -1689,7 +1685,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
     const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
     const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
-    const void *srow = reinterpret_cast<const char *>(f.stash_row) + ((flip ? f.nR : 0) + ppos) * (N32 ? 4u : 8u);
+    const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const uint64_t cap = a.out_capacity;
     const uint64_t lt = lanemask_lt();
@@ -1719,8 +1715,9 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
             const uint32_t i = g * 256u + k * WAVE + lane;
             const bool ok = i < un.count;
             c[k] = ok ? (scnt[i] & 0x7fu) : 0;
-            first[k] = ok ? fj_stash_get<N32>(srow, i) : make_uint2(0, 0);
-            prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
+            first[k] = ok ? srow[i] : make_uint2(0, 0);
+            if (N32) { prow[k] = make_uint2(first[k].y, 0u); first[k].y = 0u; }
+            else     prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
         }
         // the group's table row: lane 0 its start in the unit's output, lane j the run start of ordinal j
         uint32_t tbl_v = 0;
@@ -1850,7 +1847,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     X.hs = hs0;
     X.dirw = X.ent + bcp + 8u;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
-    void *srow = reinterpret_cast<char *>(f.stash_row) + ((flip ? f.nR : 0) + ppos) * (N32 ? 4u : 8u);
+    uint2 *srow = reinterpret_cast<uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
     const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
     FjGather G;
     G.init(bd, bc);
@@ -1891,7 +1888,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
                 // this tuple was a different key, so phase 2 must verify its candidates again
                 scnt[i] = (uint8_t)(min(c[k], 127u) | (fp[k] ? 0x80u : 0u));
-                fj_stash_put<N32>(srow, i, flo[k], fhi[k]);
+                fj_stash_put<N32>(srow, i, flo[k], fhi[k], q[k].z);
             }
             mine += c[k];
             needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
@@ -1979,8 +1976,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 const uint32_t sb = okk[h][k] ? scnt[i] : 0;
                 c[h][k] = sb & 0x7fu;
                 fpt[h][k] = (sb & 0x80u) != 0;
-                const uint2 fr = okk[h][k] ? fj_stash_get<N32>(srow, i) : make_uint2(0, 0);
-                flo[h][k] = fr.x; fhi[h][k] = fr.y;
+                const uint2 fr = okk[h][k] ? srow[i] : make_uint2(0, 0);
+                flo[h][k] = fr.x; fhi[h][k] = N32 ? 0u : fr.y;
             }
         }
 #pragma unroll
