@@ -366,7 +366,10 @@ def main():
                 pm = json.load(open(cands[-1]))
                 for kname, kv in pm.items():
                     if "k_join_fused" in kname and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
-                        traffic = int((kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024)
+                        t = int((kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024)
+                        if traffic is not None and t <= traffic:
+                            continue                      # the instantiation that returned at once (other stash width)
+                        traffic = t
                         traffic_src = ("%s: FETCH_SIZE + WRITE_SIZE of the last dispatch, uncorrected (8 B/lane key streams and "
                                        "16 B divergent gathers are not the calibrated 16 B/lane streaming case of the guide)"
                                        % os.path.basename(cands[-1]))

@@ -1929,10 +1929,13 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         __syncthreads();
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 5] = __builtin_amdgcn_s_memrealtime();
         if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
         else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         pend = 0xffffffffu;
         __syncthreads();
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     }
     if (emitting && !unit_needs_index) {              // this unit's emit pass needs no index: defer it
         pend = u;

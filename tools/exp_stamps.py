@@ -28,5 +28,9 @@ print("span (first start -> last end): %.1f us" % us(t[:, 4].max() - t0))
 for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("chain+barrier", 2, 3), ("phase2", 3, 4), ("unit total", 0, 4)):
     d = us(t[:, b] - t[:, a])
     print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+ok = t[:, 5] > 0
+d = us(t[ok, 6] - t[ok, 5]); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (thread 0's own emit span)" % ("deferred emit (w0)", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+ok7 = t[:, 7] > 0
+d = us(t[ok7, 7] - t[ok7, 2]); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (w0 after phase 1 -> all waves through the previous unit's emit)" % ("ph1 skew + prev emit", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 starts = np.sort(us(t[:, 0] - t0))
 print("start times of units 0,255,256,511,1024,4095: ", [round(float(starts[i]), 1) for i in (0, 255, 256, 511, 1024, units - 1)])
