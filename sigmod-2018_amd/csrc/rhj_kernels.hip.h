@@ -1800,6 +1800,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
     __shared__ uint32_t sh_u;
     __shared__ uint32_t sh_ovf;
+    __shared__ uint32_t sh_grab;
     __shared__ uint32_t sh_pick;
     __shared__ uint64_t sh_base;
     __shared__ uint32_t wsum[FJ_WAVES];
@@ -1818,7 +1819,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 
     for (uint32_t iter = 0;; ++iter) {
     __syncthreads();
-    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; }
+    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; sh_grab = 0; }
     __syncthreads();
     const uint32_t u = sh_u;
     if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
@@ -1867,23 +1868,31 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
     uint32_t mine = 0;
     bool needs_index = false;                         // the emit pass must walk the index again
-    for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_BATCH) {
+    // The waves take 256-tuple groups from a workgroup counter: with a fixed share per wave the barrier
+    // behind this loop waited 20 us of a 156 us unit for the slowest wave's gathers.
+    const uint32_t ngroups1 = (un.count + 255u) >> 8;
+    for (;;) {
+        uint32_t grp = 0;
+        if (lane == 0) grp = atomicAdd(&sh_grab, 1u);
+        grp = __builtin_amdgcn_readfirstlane(grp);
+        if (grp >= ngroups1) break;
+        const uint32_t t0 = grp << 8;
         uint4 q[FJ_V];
         bool okk[FJ_V];
         uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
         bool fp[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
-            const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
+            const uint32_t i = t0 + k * WAVE + lane;
             okk[k] = i < un.count;
             q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
         }
-        O.gid = (t0 >> 8) + w;
+        O.gid = grp;
         if (RES) fj_count_batch<true, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
         else     fj_count_batch<false, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
-            const uint32_t i = t0 + w * (WAVE * FJ_V) + k * WAVE + lane;
+            const uint32_t i = t0 + k * WAVE + lane;
             if (i < un.count) {
                 // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
                 // this tuple was a different key, so phase 2 must verify its candidates again
