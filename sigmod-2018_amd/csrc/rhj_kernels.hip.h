@@ -1674,7 +1674,7 @@ template <bool N32> __device__ __forceinline__ void fj_stash_put(uint2 *srow, ui
 // zero or one match (the foreign-key case), offsets come from ballots.
 template <bool DUP, bool N32>
 __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum,
-                                               const uint64_t *ovf, uint32_t *table)
+                                               const uint64_t *ovf, uint32_t *table, uint32_t *grab)
 {
     constexpr int V = FJ_V;                           // a wave's step is one 256-tuple group of phase 1
     const JoinArgs &a = f.j;
@@ -1700,6 +1700,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
         uint32_t tot;
         uint32_t ex = wave_excl_scan_u32(v, &tot);
         __syncthreads();                              // wsum reuse
+        if (t == 0) *grab = 0;
         if (lane == 0) wsum[w] = tot;
         __syncthreads();
         for (uint32_t i = 0; i < w && i < FJ_GROUPS / WAVE; ++i) ex += wsum[i];
@@ -1707,7 +1708,11 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
         __syncthreads();
     }
 
-    for (uint32_t g = w; g < ngroups; g += FJ_WAVES) {
+    for (;;) {                                        // groups are handed out as in phase 1
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(grab, 1u);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
         uint32_t c[V];
         uint2 first[V], prow[V];
 #pragma unroll
@@ -1939,8 +1944,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         }
         __syncthreads();
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
-        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         pend = 0xffffffffu;
         __syncthreads();
@@ -2088,8 +2093,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
             }
         }
         __syncthreads();
-        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
-        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table);
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
     }
 }
 
