@@ -7,8 +7,9 @@ os.environ["RHJ_STAMPS"] = "1"
 os.environ.setdefault("RHJ_LIB", os.path.join("sigmod-2018_amd", "librhj_instr.so"))
 mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
 nR, nS = [int(x) for x in sys.argv[1:3]]
-w = dict(nR=nR, nS=nS, bits=12, dist="uniform")
-rhj.set_bits(12)
+bits = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+w = dict(nR=nR, nS=nS, bits=bits, dist="uniform")
+rhj.set_bits(bits)
 R, S = bench.make_relations(w, rhj.dev, 1234)
 cap = max(nR, nS)
 out = torch.empty((cap, 2), dtype=torch.int64, device=rhj.dev)
@@ -29,8 +30,11 @@ for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("chain+barrier", 2, 3
     d = us(t[:, b] - t[:, a])
     print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 ok = t[:, 5] > 0
-d = us(t[ok, 6] - t[ok, 5]); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (thread 0's own emit span)" % ("deferred emit (w0)", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+d = us(t[ok, 6] - t[ok, 5]) if ok.any() else np.zeros(1); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (thread 0's own emit span)" % ("deferred emit (w0)", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 ok7 = t[:, 7] > 0
 d = us(t[ok7, 7] - t[ok7, 2]); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (w0 after phase 1 -> all waves through the previous unit's emit)" % ("ph1 skew + prev emit", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 starts = np.sort(us(t[:, 0] - t0))
-print("start times of units 0,255,256,511,1024,4095: ", [round(float(starts[i]), 1) for i in (0, 255, 256, 511, 1024, units - 1)])
+print("start times of units 0,255,256,511,1024,last: ", [round(float(starts[min(i, units - 1)]), 1) for i in (0, 255, 256, 511, 1024, units - 1)])
+if units <= 256:
+    ends = us(t[:, 6].max() - t0) if (t[:, 6] > 0).any() else 0
+    print("last emit end %.1f us; per-stamp medians from kernel start: %s" % (ends, [round(float(np.median(us(t[:, k] - t0))), 1) for k in range(7)]))
