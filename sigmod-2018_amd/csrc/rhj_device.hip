@@ -569,6 +569,13 @@ int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t 
     return rc;
 }
 
+// k_filter_write is grid-stride, one wave per two tiles: enough workgroups to fill the chip a few times over
+unsigned filter_write_grid(uint64_t tiles)
+{
+    const uint64_t want = (tiles + 7) / 8, cap = (uint64_t)g.cus * 32;
+    return (unsigned)(want < cap ? want : cap);
+}
+
 int op_code(char op)
 {
     return op == '<' ? 0 : op == '>' ? 1 : op == '=' ? 2 : -1;
@@ -597,7 +604,7 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
     RHJ_LAUNCH(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
                        (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
     if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
-    RHJ_LAUNCH(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
+    RHJ_LAUNCH(k_filter_write, dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
                        (const uint64_t *)g.fbase.p, d_out);
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
@@ -625,7 +632,7 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
     RHJ_LAUNCH(k_filter_mask_eq2, dim3((unsigned)tiles), dim3(256), 0, g.stream, colA, selA, colB, selB, n,
                (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
     if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
-    RHJ_LAUNCH(k_filter_write, dim3((unsigned)tiles), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
+    RHJ_LAUNCH(k_filter_write, dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
                        (const uint64_t *)g.fbase.p, d_out);
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
