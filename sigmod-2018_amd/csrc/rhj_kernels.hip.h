@@ -2236,42 +2236,11 @@ __global__ __launch_bounds__(256) void k_filter_mask_eq2(const uint64_t *colA, c
 // no barrier: lane l owns the two mask words (even / odd elements) of one 128-element round, 32 rounds per tile.
 //   few hits (<= FILTER_SPARSE per two tiles): every lane walks its own set bits in element order and stores them
 //     behind its exclusive prefix — the work is proportional to the hits, a tile pair without any costs one load;
-//   many hits: the tiles' eight 1024-element slices go through filter_write_slice, whose stores are coalesced.
+//   many hits: the wave goes through its 64 rounds one by one (the owning lane's masks and start are broadcast),
+//     so that its stores are coalesced.
 // (One workgroup per tile with the slice code alone: 98 us for 400 M rows without a hit — workgroup dispatch —
 // and 216 us at 1 % selectivity — 450 vector instructions per slice whatever the number of hits.)
 constexpr uint32_t FILTER_SPARSE = 1024;
-
-__device__ __forceinline__ void filter_write_slice(uint64_t sl, uint64_t n, const uint64_t *masks, uint64_t tbase, uint64_t *out,
-                                                   uint32_t lane, uint64_t lt)
-{
-    const uint64_t wbase = sl * FILTER_WAVE_ELEMS;
-    const uint32_t q = (uint32_t)(sl & (FILTER_TILE / FILTER_WAVE_ELEMS - 1));
-    uint64_t mine = 0, pw = 0;                         // lane j < 16 holds mask word j of this slice
-    if (lane < 2 * FILTER_ROUNDS && wbase + (uint64_t)(lane >> 1) * 2 * WAVE < n) mine = masks[(wbase >> 6) + lane];
-    if (lane < q * 2 * FILTER_ROUNDS) pw = masks[((wbase >> 6) - q * 2 * FILTER_ROUNDS) + lane];   // earlier slices of the tile
-    if (__ballot(mine != 0) == 0) return;
-    const uint32_t pc = (uint32_t)__popcll(mine);
-    uint32_t incl = pc;                                // inclusive scan over the 16 word counts
-#pragma unroll
-    for (int d = 1; d < 2 * FILTER_ROUNDS; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += y;
-    }
-    uint32_t prev = (uint32_t)__popcll(pw);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) prev += __shfl_xor(prev, d, 64);
-    const uint64_t base = tbase + prev;
-#pragma unroll
-    for (int k = 0; k < FILTER_ROUNDS; ++k) {
-        const uint64_t me = __shfl(mine, 2 * k, 64), mo = __shfl(mine, 2 * k + 1, 64);
-        const uint32_t before_round = __shfl(incl - pc, 2 * k, 64);
-        const uint32_t before = before_round + (uint32_t)__popcll(me & lt) + (uint32_t)__popcll(mo & lt);
-        const uint64_t i = wbase + (uint64_t)k * 2 * WAVE + 2 * lane;
-        const uint32_t e = (uint32_t)((me >> lane) & 1ull);
-        if (e) out[base + before] = i;
-        if ((mo >> lane) & 1ull) out[base + before + e] = i + 1;
-    }
-}
 
 __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t *masks, const uint64_t *tile_base,
                                                       uint64_t *out)
@@ -2281,7 +2250,6 @@ __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t
     const uint64_t ntasks = (ntiles + 1) / 2;
     const uint64_t stride = (uint64_t)gridDim.x * (256 / WAVE);
     const uint64_t lt = lanemask_lt();
-    constexpr uint32_t SLICES = FILTER_TILE / FILTER_WAVE_ELEMS;
     for (uint64_t task = (uint64_t)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); task < ntasks; task += stride) {
         const uint64_t tile = 2 * task + (lane >> 5);
         const uint64_t ebase = tile * FILTER_TILE + (uint64_t)(lane & 31u) * (2 * WAVE);    // first element of this lane's round
@@ -2309,10 +2277,20 @@ __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t
                 if (odd) mo &= mo - 1; else me &= me - 1;
             }
         } else {
-            const uint64_t tb0 = __shfl(tb, 0, 64), tb1 = __shfl(tb, 32, 64);
-            for (uint32_t q = 0; q < 2 * SLICES; ++q) {
-                const uint64_t sl = task * (2 * SLICES) + q;
-                if (sl * FILTER_WAVE_ELEMS < n) filter_write_slice(sl, n, masks, q < SLICES ? tb0 : tb1, out, lane, lt);
+            // many hits: round by round (lane r's masks and start broadcast to the wave), coalesced stores
+            const uint64_t start = tb + (incl - pc) - (lane >= 32 ? t0 : 0u);
+            const uint32_t melo = (uint32_t)me, mehi = (uint32_t)(me >> 32), molo = (uint32_t)mo, mohi = (uint32_t)(mo >> 32);
+            const uint32_t stlo = (uint32_t)start, sthi = (uint32_t)(start >> 32);
+            for (uint32_t r = 0; r < WAVE; ++r) {
+                const uint64_t mer = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mehi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)melo, (int)r);
+                const uint64_t mor = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mohi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)molo, (int)r);
+                if ((mer | mor) == 0) continue;
+                const uint64_t st = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sthi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)stlo, (int)r);
+                const uint32_t before = (uint32_t)__popcll(mer & lt) + (uint32_t)__popcll(mor & lt);
+                const uint64_t i = task * (2 * FILTER_TILE) + (uint64_t)r * (2 * WAVE) + 2 * lane;
+                const uint32_t e = (uint32_t)((mer >> lane) & 1ull);
+                if (e) out[st + before] = i;
+                if ((mor >> lane) & 1ull) out[st + before + e] = i + 1;
             }
         }
     }
