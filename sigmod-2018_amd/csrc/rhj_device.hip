@@ -449,11 +449,15 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             // the resident variant only when an average bucket could fit beside the index (~7.4 K tuples)
             // Both stash widths are launched; the one that does not match the partition's row-id decision
             // (summary->wide_row_ids, known only on the device) returns at once.
+            // (One-pass partitions and forced-wide runs are wide by construction: the host knows, one launch.)
+            const bool maybe_narrow = bits > PT_MAX_BITS && !force_wide;
             if (nmin / bins <= 7000 && !g.no_resident) {
-                RHJ_LAUNCH((k_join_fused<true, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                if (maybe_narrow)
+                    RHJ_LAUNCH((k_join_fused<true, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
                 RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             } else {
-                RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                if (maybe_narrow)
+                    RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             }
             RHJ_LAUNCH(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
