@@ -751,16 +751,16 @@ int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, 
 void rhj_release(void)
 {
     if (!g.ready) return;
-    hipStreamSynchronize(g.stream);
+    (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
                   &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
-    for (Buf *b : all) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
-    for (auto &kv : g.columns) hipFree(kv.second);
+    for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    for (auto &kv : g.columns) (void)hipFree(kv.second);
     g.columns.clear();
-    for (auto &kv : g.free_blocks) hipFree(kv.second);
+    for (auto &kv : g.free_blocks) (void)hipFree(kv.second);
     g.free_blocks.clear();
-    for (auto &kv : g.live_blocks) hipFree(kv.first);
+    for (auto &kv : g.live_blocks) (void)hipFree(kv.first);
     g.live_blocks.clear();
 }
 
@@ -838,7 +838,7 @@ static void *column_device(const uint64_t *host_col, uint64_t rows)
     if (it != g.columns.end()) return it->second;
     void *d = nullptr;
     if (hipMalloc(&d, (rows ? rows : 1) * 8) != hipSuccess) return nullptr;
-    if (hipMemcpyAsync(d, host_col, rows * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) { hipFree(d); return nullptr; }
+    if (hipMemcpyAsync(d, host_col, rows * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
     g.columns[key] = d;
     return d;
 }
