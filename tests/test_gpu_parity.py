@@ -311,3 +311,34 @@ def test_above_2_31_tuples(rhj):
     del R, S
     rhj.lib.rhj_release()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [1, 63, 127, 128, 129, 4095, 4096, 4097, 8191, 8192, 8193, 12289, 100003, 1 << 20])
+def test_filter_sizes_and_densities(rhj, n):
+    """The index-list pass works per pair of 4096-element tiles and switches from walking set bits to the
+    coalesced round-by-round form above 1024 hits per pair: sizes around the tile / pair / round edges, hit
+    densities on both sides of the switch (incl. none, all, exactly 1024 and 1025 per pair), direct and
+    through a row-id vector, against numpy (Filter(): filter.c:92-190, ascending indices)."""
+    torch = rhj.torch
+    rng = np.random.RandomState(n)
+    col = rng.randint(0, 1000, n).astype(np.uint64)
+    cases = [("<", 0), ("<", 10), ("<", 124), ("<", 126), ("<", 500), ("<", 1000), (">", 998), ("=", 7)]
+    dcol = torch.from_numpy(col.view(np.int64)).to(rhj.dev)
+    for op, v in cases:
+        want = np.nonzero(col < v if op == "<" else col > v if op == ">" else col == v)[0].astype(np.uint64)
+        got = rhj.filter_device(dcol, op, v).cpu().numpy().view(np.uint64)
+        assert len(got) == len(want) and (got == want).all(), (n, op, v)
+    if n >= 8192:
+        # exactly 1024 and 1025 hits in the first tile pair, nothing elsewhere
+        for k in (1024, 1025):
+            c2 = np.full(n, 5, dtype=np.uint64)
+            pos = np.sort(rng.choice(8192, k, replace=False))
+            c2[pos] = 1
+            got = rhj.filter_device(torch.from_numpy(c2.view(np.int64)).to(rhj.dev), "<", 2).cpu().numpy().view(np.uint64)
+            assert (got == pos.astype(np.uint64)).all(), (n, k)
+    sel = rng.randint(0, n, max(1, n // 2)).astype(np.uint64)
+    dsel = torch.from_numpy(sel.view(np.int64)).to(rhj.dev)
+    for op, v in (("<", 10), ("<", 500)):
+        want = np.nonzero(col[sel] < v)[0].astype(np.uint64)
+        got = rhj.filter_device(dcol, op, v, dsel).cpu().numpy().view(np.uint64)
+        assert len(got) == len(want) and (got == want).all(), (n, op, v, "sel")
