@@ -43,7 +43,7 @@ static void *sink_chunk(void *ctx, uint64_t elems)
     list_sink *s = (list_sink *)ctx;
     rhj_result *node = (rhj_result *)malloc(sizeof(rhj_result));
     if (!node) { s->failed = 1; return NULL; }
-    node->buff = (char *)malloc(elems * s->elem ? elems * s->elem : 1);
+    node->buff = (char *)malloc(elems * s->elem != 0 ? elems * s->elem : 1);
     if (!node->buff) { free(node); s->failed = 1; return NULL; }
     node->next = NULL;
     node->current_load = elems;

@@ -6,6 +6,7 @@
 // an error; a missing GPU makes every entry point fail.
 #include "rhj_kernels.hip.h"
 #include "rhj_internal.h"
+#include <mutex>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -655,8 +656,13 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
 
 extern "C" {
 
+static std::recursive_mutex g_api_mutex;
+void rhj_api_lock(void) { g_api_mutex.lock(); }
+void rhj_api_unlock(void) { g_api_mutex.unlock(); }
+
 int rhj_set_radix_bits(int bits)
 {
+    RhjApiLock api_lock;
     if (bits < 1 || bits > MAX_BITS) return -1;
     g.bits = bits;
     return 0;
@@ -670,17 +676,20 @@ void rhj_set_resident(int on) { g.no_resident = !on; }
 /* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */
 int rhj_debug_stamps(uint64_t *host, uint64_t units)
 {
+    RhjApiLock api_lock;
     if (!g.dbg.p) return -1;
     return hipMemcpy(host, g.dbg.p, units * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 int rhj_set_device(int ordinal)
 {
+    RhjApiLock api_lock;
     if (g.ready) return -1;
     g.device = ordinal;
     return 0;
 }
 void rhj_set_stream(void *s)
 {
+    RhjApiLock api_lock;
     // s is a hipStream_t; NULL is HIP's default (null) stream, which is what PyTorch's default
     // stream is: work the caller queued there is ordered before ours.  Until this is called the
     // library launches on a non-blocking stream of its own.
@@ -694,6 +703,7 @@ const char *rhj_version(void) { return "rhj-mi355x 0.1 (gfx950)"; }
 int rhj_join_device(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple *d_out,
                     uint64_t out_capacity, uint64_t *matches)
 {
+    RhjApiLock api_lock;
     uint64_t m = 0;
     const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, false, nullptr, &m);
     if (matches) *matches = m;
@@ -702,6 +712,7 @@ int rhj_join_device(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uin
 
 int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, uint64_t *h_hist, int64_t *h_psum)
 {
+    RhjApiLock api_lock;
     if (ctx_init()) return -1;
     const int bits = g.bits;
     const uint32_t bins = 1u << bits;
@@ -742,6 +753,7 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
 int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char op, uint64_t value,
                       uint64_t *d_out, uint64_t *hits)
 {
+    RhjApiLock api_lock;
     uint64_t h = 0;
     const int rc = filter_device(d_col, d_sel, n, op, value, d_out, false, nullptr, &h);
     if (hits) *hits = h;
@@ -750,6 +762,7 @@ int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, 
 
 void rhj_release(void)
 {
+    RhjApiLock api_lock;
     if (!g.ready) return;
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
@@ -771,6 +784,7 @@ void rhj_release(void)
 int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS, uint64_t *matches,
                   void *(*alloc_chunk)(void *ctx, uint64_t pairs), void *ctx, uint64_t node_pairs)
 {
+    RhjApiLock api_lock;
     *matches = 0;
     if (ctx_init()) return -1;
     if (nR == 0 || nS == 0) return 0;
@@ -845,6 +859,7 @@ static void *column_device(const uint64_t *host_col, uint64_t rows)
 
 int rhj_register_relation_map(const rhj_relation_map *map, int num_relations)
 {
+    RhjApiLock api_lock;
     if (ctx_init()) return -1;
     for (int r = 0; r < num_relations; ++r)
         for (uint64_t c = 0; c < map[r].num_columns; ++c)
@@ -858,6 +873,7 @@ int rhj_register_relation_map(const rhj_relation_map *map, int num_relations)
 int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel, uint64_t n, char op, uint64_t value,
                     uint64_t *hits, void *(*alloc_chunk)(void *ctx, uint64_t ids), void *ctx, uint64_t node_ids)
 {
+    RhjApiLock api_lock;
     *hits = 0;
     if (ctx_init()) return -1;
     if (op_code(op) < 0) return -3;
@@ -897,6 +913,7 @@ uint64_t rhj_host_node_pairs(void) { return g.node_pairs; }
 // block freed with work still queued came back with stale contents visible to later kernels.)
 void *rhj_dev_alloc(size_t bytes)
 {
+    RhjApiLock api_lock;
     if (ctx_init()) return nullptr;
     size_t want = bytes < 256 ? 256 : bytes;
     if (want <= ((size_t)1 << 20)) { size_t c = 256; while (c < want) c <<= 1; want = c; }      // power-of-two classes
@@ -924,6 +941,7 @@ void *rhj_dev_alloc(size_t bytes)
 }
 void rhj_dev_free(void *p)
 {
+    RhjApiLock api_lock;
     if (!p) return;
     auto it = g.live_blocks.find(p);
     if (it == g.live_blocks.end()) return;
@@ -933,17 +951,20 @@ void rhj_dev_free(void *p)
 void *rhj_dev_stream(void) { return ctx_init() ? nullptr : (void *)g.stream; }
 const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows)
 {
+    RhjApiLock api_lock;
     if (ctx_init()) return nullptr;
     return (const uint64_t *)column_device(host_col, rows);
 }
 int rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out, uint64_t *matches)
 {
+    RhjApiLock api_lock;
     *out = nullptr; *matches = 0;
     return join_device(d_R, nR, d_S, nS, nullptr, 0, true, out, matches);
 }
 int rhj_filter_eq2_device(const uint64_t *d_colA, const uint64_t *d_selA, const uint64_t *d_colB, const uint64_t *d_selB,
                           uint64_t n, uint64_t *d_out, uint64_t *hits)
 {
+    RhjApiLock api_lock;
     uint64_t h = 0;
     const int rc = filter_eq2_device(d_colA, d_selA, d_colB, d_selB, n, d_out, &h);
     if (hits) *hits = h;

@@ -246,15 +246,28 @@ extern "C" {
 
 // ------------------------------------------------------------------ identity of resident objects
 
-int rhj_resident_relation(const rhj_relation *rel) { return rel && g_rel.count(rel); }
-int rhj_resident_result(const rhj_result *res) { return res && g_res.count(res); }
-int rhj_resident_inter(const rhj_inter_res *head) { return head && g_inter.count(head); }
+int rhj_resident_relation(const rhj_relation *rel)
+{
+    RhjApiLock api_lock;
+    return rel && g_rel.count(rel);
+}
+int rhj_resident_result(const rhj_result *res)
+{
+    RhjApiLock api_lock;
+    return res && g_res.count(res);
+}
+int rhj_resident_inter(const rhj_inter_res *head)
+{
+    RhjApiLock api_lock;
+    return head && g_inter.count(head);
+}
 
 // ------------------------------------------------------------------ device entry points
 
 int rhj_gather_tables_device(uint64_t *const *dst, const uint64_t *const *src, int ntab, const uint64_t *idx,
                              int idx_stride, uint64_t n)
 {
+    RhjApiLock api_lock;
     if (ntab < 0 || ntab > MAX_TABLES) return -2;
     if (n == 0 || ntab == 0) return 0;
     GatherArgs a;
@@ -266,6 +279,7 @@ int rhj_gather_tables_device(uint64_t *const *dst, const uint64_t *const *src, i
 
 int rhj_build_relation_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, rhj_tuple *d_tuples)
 {
+    RhjApiLock api_lock;
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_build_relation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), d_col, d_sel, n, d_tuples);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -273,6 +287,7 @@ int rhj_build_relation_device(const uint64_t *d_col, const uint64_t *d_sel, uint
 
 int rhj_sum_gather_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, uint64_t *sum)
 {
+    RhjApiLock api_lock;
     *sum = 0;
     if (n == 0) return 0;
     unsigned long long *d_sum = (unsigned long long *)rhj_dev_alloc(8);
@@ -293,6 +308,7 @@ int rhj_sum_gather_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t
 
 rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS)
 {
+    RhjApiLock api_lock;
     rhj_result_tuple *out = nullptr;
     uint64_t m = 0;
     TRACE("RadixHashJoin %lu x %lu", (unsigned long)relR->num_tuples, (unsigned long)relS->num_tuples);
@@ -309,6 +325,7 @@ rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS)
 
 rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, rhj_relation_map *map, int *query_relations)
 {
+    RhjApiLock api_lock;
     const int relation = filter_p->relation;
     const rhj_relation_map *rm = &map[query_relations[relation]];
     const char op = filter_p->comperator;
@@ -331,6 +348,7 @@ rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, 
 
 void rhj_resident_free_result(rhj_result *res)
 {
+    RhjApiLock api_lock;
     while (res) {
         rhj_result *t = res;
         res = res->next;
@@ -342,6 +360,7 @@ void rhj_resident_free_result(rhj_result *res)
 
 void rhj_resident_free_relation(rhj_relation *rel)
 {
+    RhjApiLock api_lock;
     g_rel.erase(rel);
     rhj_dev_free(rel->tuples);
     free(rel);
@@ -350,6 +369,7 @@ void rhj_resident_free_relation(rhj_relation *rel)
 // element `index` of a resident result, for the results.c accessors (results.c:48-64, :126-142)
 int rhj_resident_fetch(const rhj_result *res, uint64_t elem_bytes, uint64_t index, void *dst)
 {
+    RhjApiLock api_lock;
     if (index >= res->current_load) return -1;
     hipStream_t s = stream();
     if (hipMemcpyAsync(dst, res->buff + index * elem_bytes, elem_bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
@@ -360,6 +380,7 @@ int rhj_resident_fetch(const rhj_result *res, uint64_t elem_bytes, uint64_t inde
 
 int InitInterData(rhj_inter_data **head, int num_of_relations, int num_tuples)      // inter_res.c:10-15
 {
+    RhjApiLock api_lock;
     (*head) = (rhj_inter_data *)malloc(sizeof(rhj_inter_data));
     (*head)->num_tuples = (uint64_t)num_tuples;
     (*head)->table = (uint64_t **)calloc((size_t)num_of_relations, sizeof(uint64_t *));
@@ -368,6 +389,7 @@ int InitInterData(rhj_inter_data **head, int num_of_relations, int num_tuples)  
 
 void FreeInterData(rhj_inter_data *head, int num_of_relations)                       // inter_res.c:17-24
 {
+    RhjApiLock api_lock;
     for (int i = 0; i < num_of_relations; ++i)
         if (head->table[i] != nullptr) rhj_dev_free(head->table[i]);
     free(head->table);
@@ -376,6 +398,7 @@ void FreeInterData(rhj_inter_data *head, int num_of_relations)                  
 
 int InitInterResults(rhj_inter_res **head, int num_of_rel)                           // inter_res.c:26-32
 {
+    RhjApiLock api_lock;
     (*head) = (rhj_inter_res *)malloc(sizeof(rhj_inter_res));
     (*head)->next = nullptr;
     (*head)->num_of_relations = num_of_rel;
@@ -386,6 +409,7 @@ int InitInterResults(rhj_inter_res **head, int num_of_rel)                      
 
 void FreeInterResults(rhj_inter_res *var)                                            // inter_res.c:175-180
 {
+    RhjApiLock api_lock;
     if (var->next != nullptr) FreeInterResults(var->next);
     FreeInterData(var->data, var->num_of_relations);
     g_inter.erase(var);
@@ -394,6 +418,7 @@ void FreeInterResults(rhj_inter_res *var)                                       
 
 void PrintInterResults(rhj_inter_res *head)                                          // inter_res.c:154-173
 {
+    RhjApiLock api_lock;
     int index = 0;
     hipStream_t s = stream();
     while (head != nullptr) {
@@ -422,6 +447,7 @@ void PrintInterResults(rhj_inter_res *head)                                     
 
 int InsertJoinToInterResults(rhj_inter_res *head, int rel1, int rel2, rhj_result *res)   // inter_res.c:34-152
 {
+    RhjApiLock api_lock;
     const uint64_t count = result_count(res);
     const uint64_t *pairs = result_ids(res);                    // {row_idR, row_idS} per element
     TRACE("InsertJoinToInterResults rel %d %d pairs %lu", rel1, rel2, (unsigned long)count);
@@ -500,6 +526,7 @@ rhj_result *SelfJoin(int given_rel, int column1, int column2, rhj_inter_res **in
 
 void Merge(rhj_inter_res **head, rhj_inter_res **node, int rel_num)                // inter_res.c:287-318
 {
+    RhjApiLock api_lock;
     rhj_inter_res *h = *head, *victim = (*node)->next;
     const int nrel = h->num_of_relations;
     TRACE("Merge on rel %d: head rows %lu, victim rows %lu", rel_num, (unsigned long)h->data->num_tuples, (unsigned long)victim->data->num_tuples);
@@ -530,6 +557,7 @@ void Merge(rhj_inter_res **head, rhj_inter_res **node, int rel_num)             
 
 void MergeInterNodes(rhj_inter_res **inter)                                         // inter_res.c:265-284
 {
+    RhjApiLock api_lock;
     if ((*inter)->next == nullptr) return;
     for (int i = 0; i < (*inter)->num_of_relations; i++) {
         rhj_inter_res *temp = (*inter);
@@ -545,6 +573,7 @@ void MergeInterNodes(rhj_inter_res **inter)                                     
 
 void CalculateQueryResults(rhj_inter_res *inter, rhj_relation_map *map, rhj_batch_listnode *query)   // inter_res.c:320-339
 {
+    RhjApiLock api_lock;
     TRACE("CalculateQueryResults");
     trace_nodes(inter);
     for (int i = 0; i < query->views->num_of_elements; i++) {
@@ -562,6 +591,7 @@ void CalculateQueryResults(rhj_inter_res *inter, rhj_relation_map *map, rhj_batc
 
 void PrintNullResults(rhj_batch_listnode *query)                                    // inter_res.c:341-350
 {
+    RhjApiLock api_lock;
     TRACE("PrintNullResults");
     for (int i = 0; i < query->views->num_of_elements; i++) {
         printf("NULL");
@@ -572,6 +602,7 @@ void PrintNullResults(rhj_batch_listnode *query)                                
 
 int AreActiveInInter(rhj_inter_res *inter, int rel1, int rel2)                      // inter_res.c:352-361
 {
+    RhjApiLock api_lock;
     while (inter != nullptr) {
         if (inter->data->table[rel1] != nullptr && inter->data->table[rel2] != nullptr) return 1;
         inter = inter->next;
@@ -607,6 +638,7 @@ int JoinInterNode(rhj_inter_res **inter, rhj_relation_map *rel_map, int rel1, in
 
 void CartesianInterResults(rhj_inter_res **inter)                                   // inter_res.c:391-428
 {
+    RhjApiLock api_lock;
     rhj_inter_res *temp = (*inter);
     if (temp->next == nullptr) return;
     TRACE("CartesianInterResults");
@@ -645,6 +677,7 @@ void CartesianInterResults(rhj_inter_res **inter)                               
 
 int InsertSingleRowIdsToInterResult(rhj_inter_res **head, int relation_num, rhj_result *res)
 {
+    RhjApiLock api_lock;
     const uint64_t count = result_count(res);
     const uint64_t *ids = result_ids(res);
     rhj_inter_res *node = *head, *last = nullptr;
@@ -675,6 +708,7 @@ int InsertSingleRowIdsToInterResult(rhj_inter_res **head, int relation_num, rhj_
 
 int rhj_column_stats_device(const uint64_t *d_col, uint64_t n, uint64_t *l, uint64_t *u, double *d)
 {
+    RhjApiLock api_lock;
     if (n == 0) { *l = *u = 0; *d = 0; return 0; }
     hipStream_t s = stream();
     unsigned long long *acc = (unsigned long long *)rhj_dev_alloc(32);      // min, max, count
@@ -708,6 +742,7 @@ int rhj_column_stats_device(const uint64_t *d_col, uint64_t n, uint64_t *l, uint
 
 int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)           // relation_map.c:13-88
 {
+    RhjApiLock api_lock;
     int i = 0;
     TRACE("InitRelationMap begins");
     while (head != nullptr) {
@@ -742,6 +777,7 @@ int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)     
 
 void FreeRelationMap(rhj_relation_map *rel_map, int map_size)                        // relation_map.c:90-98
 {
+    RhjApiLock api_lock;
     for (int i = 0; i < map_size; ++i) {
         free(rel_map[i].columns);
         free(rel_map[i].col_stats);
@@ -751,6 +787,7 @@ void FreeRelationMap(rhj_relation_map *rel_map, int map_size)                   
 
 void PrintRelationMap(rhj_relation_map *rel_map, int map_size)                       // relation_map.c:100-115
 {
+    RhjApiLock api_lock;
     for (int i = 0; i < map_size; ++i) {
         printf("Printing Relation: %d\n", i);
         printf("%lu %lu\n", (unsigned long)rel_map[i].num_tuples, (unsigned long)rel_map[i].num_columns);

@@ -23,6 +23,11 @@ const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows);   /* ca
 int   rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out,
                    uint64_t *matches);             /* *out is library-owned and valid until the next join */
 
+/* One library context per process: every entry point runs under this (recursive) lock, so calls from several
+ * host threads are serialised instead of racing on the workspace, the registries and the stream. */
+void rhj_api_lock(void);
+void rhj_api_unlock(void);
+
 /* device-resident side of the reference's entry points (rhj_inter.hip), called by rhj_abi.c */
 rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS);
 rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, rhj_relation_map *map, int *query_relations);
@@ -31,5 +36,11 @@ void rhj_resident_free_relation(rhj_relation *rel);
 int  rhj_resident_fetch(const rhj_result *res, uint64_t elem_bytes, uint64_t index, void *dst);
 #ifdef __cplusplus
 }
+struct RhjApiLock {
+    RhjApiLock() { rhj_api_lock(); }
+    ~RhjApiLock() { rhj_api_unlock(); }
+    RhjApiLock(const RhjApiLock &) = delete;
+    RhjApiLock &operator=(const RhjApiLock &) = delete;
+};
 #endif
 #endif

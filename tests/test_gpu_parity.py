@@ -342,3 +342,40 @@ def test_filter_sizes_and_densities(rhj, n):
         want = np.nonzero(col[sel] < v)[0].astype(np.uint64)
         got = rhj.filter_device(dcol, op, v, dsel).cpu().numpy().view(np.uint64)
         assert len(got) == len(want) and (got == want).all(), (n, op, v, "sel")
+
+
+def test_entry_points_from_several_host_threads(rhj, oracle):
+    """One library context per process: the entry points serialise under a lock (rhj_internal.h), so callers on
+    several host threads get the same pair lists and index lists as one caller.  (ctypes releases the GIL
+    during the calls, so the four threads really are inside the library together.)"""
+    import threading
+    rhj.set_bits(12)
+    work = []
+    for t in range(4):
+        R = oracle.generate(40000 + 1000 * t, 0, 30000, 0.0, 900 + t)
+        S = oracle.generate(90000 + 5000 * t, 1, 30000, 0.9, 950 + t)
+        col = (np.arange(300000, dtype=np.uint64) * np.uint64(2654435761 + t)) % np.uint64(1000)
+        work.append((R, S, oracle.join(R, S, 12), col, np.nonzero(col < 17 + t)[0].astype(np.uint64), 17 + t))
+    errors = []
+
+    def run(t):
+        R, S, want, col, want_ids, v = work[t]
+        try:
+            for it in range(12):
+                got = rhj.RadixHashJoin(R, S)
+                if len(got) != len(want) or not (got == want).all():
+                    errors.append("thread %d join %d differs" % (t, it))
+                    return
+                ids = rhj.Filter([col], len(col), 0, "<", v)
+                if len(ids) != len(want_ids) or not (np.asarray(ids, dtype=np.uint64) == want_ids).all():
+                    errors.append("thread %d filter %d differs" % (t, it))
+                    return
+        except Exception as e:                         # noqa: BLE001 - reported below
+            errors.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
