@@ -59,3 +59,36 @@ def test_bench_small_workload_mode_checks_and_reports(tmp_path):
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     line = json.loads(res.stdout.decode().strip().splitlines()[-1])
     assert line["config"]["answers"] == "identical to small.result" and line["config"]["queries"] == 50 and line["value"] > 0
+
+
+@pytest.mark.parametrize("bits", ["4", "10"])
+def test_scaled_workload_matches_the_reference_engine(golden, tmp_path, bits):
+    """`small` with every relation four copies of itself (copy c shifted by c * 2^24 in every column, so joins
+    match inside a copy only): the reference engine as compiled from its own sources (THREADS 1, the
+    authoritative mode) and the device-resident configuration answer the same 50 queries and must print the
+    same 50 lines — at the engine's 4 radix bits and at 10, where the joins take the two-pass partition and the
+    view sums must not change (they do not depend on the radix)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "radixhash_t1")
+    eng = ENGINES["radixhash_rhj_resident"]
+    if not (os.path.exists(ref) and os.path.exists(eng)):
+        pytest.skip("oracle/_ref engines not built (need /root/reference at build time)")
+    K, stride = 4, np.uint64(1 << 24)
+    names = []
+    for i in range(14):
+        cols = golden.small_relations["r%d" % i].astype("<u8")
+        assert int(cols.max()) < int(stride)
+        big = np.concatenate([cols + np.uint64(c) * stride for c in range(K)], axis=1)
+        with open(tmp_path / ("r%d" % i), "wb") as f:
+            np.array([big.shape[1], big.shape[0]], dtype="<u8").tofile(f)
+            np.ascontiguousarray(big).tofile(f)
+        names.append("r%d" % i)
+    stdin = ("\n".join(names) + "\nDone\n" + "\n".join(golden.small["work_lines"]) + "\n").encode()
+    outs = {}
+    for name, exe, env in (("reference", ref, dict(os.environ)), ("resident", eng, dict(os.environ, RHJ_RADIX_BITS=bits))):
+        res = subprocess.run([exe], input=stdin, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             timeout=900)
+        assert res.returncode == 0, (name, res.stderr.decode()[-2000:])
+        outs[name] = res.stdout.decode().splitlines()
+    assert len(outs["reference"]) == len(outs["resident"]) == 50
+    bad = [(i, a, b) for i, (a, b) in enumerate(zip(outs["reference"], outs["resident"])) if a != b]
+    assert not bad, bad[:5]
