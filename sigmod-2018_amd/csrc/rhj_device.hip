@@ -680,6 +680,29 @@ int rhj_debug_stamps(uint64_t *host, uint64_t units)
     if (!g.dbg.p) return -1;
     return hipMemcpy(host, g.dbg.p, units * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+#ifdef RHJ_INSTRUMENT
+/* diagnostics build only: rate of random 16-byte gathers from per-workgroup regions (tools/gather_bench.py) */
+int rhj_debug_gather_bench(uint32_t region_elems, uint32_t rounds, uint32_t stream_per_round, uint32_t wgs, float *ms)
+{
+    RhjApiLock api_lock;
+    if (ctx_init()) return -1;
+    const size_t reg_bytes = (size_t)wgs * region_elems * 16, str_bytes = (size_t)wgs * rounds * (stream_per_round ? stream_per_round : 1) * FJ_BLOCK * 16;
+    void *reg = nullptr, *str = nullptr, *sink = nullptr;
+    if (hipMalloc(&reg, reg_bytes) != hipSuccess || hipMalloc(&str, str_bytes) != hipSuccess || hipMalloc(&sink, FJ_BLOCK * 16) != hipSuccess) return -1;
+    HIP_TRY(hipMemsetAsync(reg, 1, reg_bytes, g.stream));
+    HIP_TRY(hipMemsetAsync(str, 2, str_bytes, g.stream));
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+        RHJ_LAUNCH(k_gather_bench, dim3(wgs), dim3(FJ_BLOCK), 0, g.stream, (const rhj_tuple *)reg, region_elems, rounds,
+                   (const uint4 *)str, stream_per_round, (uint4 *)sink);
+        HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+    }
+    *ms = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    (void)hipFree(reg); (void)hipFree(str); (void)hipFree(sink);
+    return 0;
+}
+#endif
 int rhj_set_device(int ordinal)
 {
     RhjApiLock api_lock;
