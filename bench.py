@@ -39,6 +39,8 @@ WORKLOADS = {
     "c4": dict(nR=100_000_000, nS=1_000_000_000, bits=14, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 14 radix bits (config leaves the radix free: 6.1 K build tuples per bucket fit LDS)"),
     "c4b15": dict(nR=100_000_000, nS=1_000_000_000, bits=15, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 15 radix bits"),
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
+    "c3b13": dict(nR=100_000_000, nS=100_000_000, bits=13, dist="uniform", name="100Mx100M uniform u64 FK, 13 radix bits (experiment)"),
+    "c3b15": dict(nR=100_000_000, nS=100_000_000, bits=15, dist="uniform", name="100Mx100M uniform u64 FK, 15 radix bits (experiment)"),
     "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
     # BASELINE configs[4]: the SIGMOD'18 `small` workload through the reference's own driver and query executor
     # linked against librhj.so (device-resident configuration); the 50 queries are dealt round-robin to the ranks
@@ -122,20 +124,12 @@ def check_properties(R, S, out, m, w):
     assert bool((b[1:] >= b[:-1]).all()), "buckets not ascending"
 
 
-def cpu_baseline(w):
-    """The reference's own code (oracle/_ref: the THREADS=1 build of rhjoin.c/preprocess.c, the
-    authoritative mode, SURVEY.md finding 4) — or, when that binary is absent, this repo's
-    restatement (oracle/rhj_oracle.c) — timed on the host cores over a bounded sample of the same
-    workload (same distribution and radix bits).  The sample grows until one call takes a few
-    seconds, so the whole leg stays around 10-30 s of CPU work on any host."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle
-    o = pyoracle.Oracle()
+def _cpu_row(o, pyoracle, w, threads, budget_s, start_nR):
+    """One timed row: the reference's own code at THREADS = `threads` on a sample of the workload that grows
+    (x4) until a single RadixHashJoin call takes a few seconds or the row's budget is spent."""
     scale = w["nS"] // w["nR"]
-    use_ref = pyoracle.ref_available(w["bits"], 1)
-    ref = pyoracle.Reference(w["bits"], 1) if use_ref else None
-    nR, best = min(w["nR"], 4_000_000 // max(scale // 2, 1)), None
-    spent = 0.0
+    ref = pyoracle.Reference(w["bits"], threads)
+    nR, best, spent = min(w["nR"], start_nR), None, 0.0
     while True:
         nS = nR * scale
         R = o.generate(nR, 3 if w["dist"] == "dense" else 0, 0, 0.0, 42)
@@ -143,26 +137,61 @@ def cpu_baseline(w):
         if w["dist"] == "dense":
             S["value"] += 1
         t = time.time()
-        if use_ref:
-            _, info = ref.join(R, S, with_info=True)
-            secs = info["seconds"]
-        else:
-            o.join(R, S, w["bits"])
-            secs = time.time() - t
+        pairs, info = ref.join(R, S, with_info=True)
         spent += time.time() - t
-        best = (nR, nS, secs)
-        del R, S
-        if secs >= 3.0 or spent >= 12.0 or nR >= w["nR"] or nR * 4 * scale * 80 > 40e9:
+        best = (nR, nS, info["seconds"], len(pairs))
+        del R, S, pairs
+        if info["seconds"] * 4 > 8.0 or spent >= budget_s or nR >= w["nR"] or nR * 4 * scale * 80 > 40e9:
             break
         nR = min(w["nR"], nR * 4)
-    nR, nS, secs = best
-    return {"value": nS / secs / 1e9, "unit": "10^9 probe tuples/s", "cores": 1,
-            "kind": "reference" if use_ref else "port",
-            "sample": "%dx%d %s, %d radix bits, one RadixHashJoin call (THREADS=1 path), %.2f s" % (
-                nR, nS, w["dist"], w["bits"], secs),
-            "host_cpus": os.cpu_count(),
-            "note": "the shipped THREADS=4 partitioner is O(buckets x N) and wrong on skew (SURVEY.md findings 3-4); "
-                    "the serial path is the reference's faster and correct mode"}
+    nR, nS, secs, m = best
+    return {"value": nS / secs / 1e9, "unit": "10^9 probe tuples/s", "cores": threads, "kind": "reference",
+            "sample": "%dx%d %s, %d radix bits, one RadixHashJoin call, %.2f s, %d pairs" % (nR, nS, w["dist"], w["bits"], secs, m)}
+
+
+def cpu_baseline(w):
+    """The reference's own code (oracle/_ref: rhjoin.c / preprocess.c / scheduler.c compiled from /root/reference,
+    N_LSB = the workload's radix bits) timed on this box's host cores over a bounded sample of the same workload
+    (same distribution and radix bits), about 10-30 s of CPU work in all.  Rows:
+      * THREADS 4 — the path as shipped (structs.h:12): scheduler.c's pthread pool running HistJob / PartitionJob /
+        JoinJob.  PartitionJob re-scans the input once per bucket it owns (preprocess.c:222-299): O(buckets x N), so
+        its RATE does not depend on the sample size — the sample's rate is the extrapolation to the full workload
+         — and it is wrong when the last bucket holds more than 1/THREADS of an input
+        (SURVEY.md finding 4: uniform and Zipf-over-hashed keys are not affected; the pair count is in the row);
+      * THREADS 16 — the same code with as many workers as this box gives one GPU's process (THREADS is a compile-time
+        #define: one prebuilt variant per count, so `nproc` itself is not available);
+      * THREADS 1 — SerialReorderArray + the bucket loop on one core: the reference's correct and, at 8+ radix bits,
+        faster mode; the parity oracle.
+    The headline fields are the as-shipped THREADS 4 row (the path north_star names); the fastest row is named too.
+    Without oracle/_ref (it cannot be built on the GPU box) the rows fall back to this repo's restatement, kind "port"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    o = pyoracle.Oracle()
+    rows = []
+    for threads, budget, start in ((4, 8.0, 250_000), (16, 6.0, 250_000), (1, 10.0, 4_000_000 // max(w["nS"] // w["nR"] // 2, 1))):
+        if pyoracle.ref_available(w["bits"], threads):
+            rows.append(_cpu_row(o, pyoracle, w, threads, budget, start))
+    if not rows:                                          # no compiled reference here: time the restatement (1 core)
+        scale = w["nS"] // w["nR"]
+        nR = min(w["nR"], 4_000_000)
+        R = o.generate(nR, 0, 0, 0.0, 42)
+        S = o.generate(nR * scale, 1, nR, 0.0, 43)
+        t = time.time()
+        o.join(R, S, w["bits"])
+        secs = time.time() - t
+        rows.append({"value": nR * scale / secs / 1e9, "unit": "10^9 probe tuples/s", "cores": 1, "kind": "port",
+                     "sample": "%dx%d, %d radix bits, oracle/rhj_oracle.c, %.2f s" % (nR, nR * scale, w["bits"], secs)})
+    head = dict(rows[0])
+    head["rows"] = rows
+    head["best"] = max(rows, key=lambda r: r["value"])
+    head["host_cpus"] = os.cpu_count()
+    try:
+        head["usable_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    head["note"] = ("headline = the reference as shipped when its THREADS-4 variant is built for these radix bits "
+                    "(rate independent of n: O(buckets x N) partitioner); `best` = the fastest reference mode")
+    return head
 
 
 def run_small(args, world, rank, local, dist):
@@ -249,12 +278,72 @@ def run_small(args, world, rank, local, dist):
         print(json.dumps(res))
 
 
+def run_strong(args, w, rhj, world, rank, backend, dist):
+    """ONE join of the workload sharded over the ranks by bucket range: the relations are replicated
+    (same seed on every rank: a device-resident column store per GPU), every rank histograms both, selects the tuples
+    of its bucket range, joins them with rhj_join_device, and the pair lists are exchanged with the exact-size
+    all-gather-v so that every rank ends with the canonical result.  Total work is fixed: "scaling": "strong"."""
+    import torch
+    shard = importlib.import_module("sigmod-2018_amd.shard")
+    ops = shard.RhjOps(rhj)
+    dev = rhj.dev
+    R, S = make_relations(w, dev, 1234)
+    gather = not args.no_gather
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    full, info = None, None
+    for _ in range(args.warmup):
+        full, info = shard.sharded_join(ops, R, S, w["bits"], gather=gather)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        del full
+        full, info = shard.sharded_join(ops, R, S, w["bits"], gather=gather)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = rhj.stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    M = sum(info["counts"]) if gather else None
+    if gather:
+        check_properties(R, S, full, M, w)                 # canonical order, every S row once, on every rank
+    if rank == 0:
+        cr, cs = info["tuples"]
+        lp = info["local_pairs"]
+        probe_bytes = 16 * (cr + cs) + 16 * lp
+        ms_probe = st["ms_probe"]
+        res = {"metric": "probe throughput (10^9 tuples/s) + achieved HBM GB/s",
+               "value": w["nS"] * args.steps / elapsed / 1e9,
+               "unit": "10^9 probe tuples/s (ONE RadixHashJoin over all ranks, inputs resident in HBM on every rank)",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": w["name"], "id": args.workload, "nR": w["nR"], "nS": w["nS"], "radix_bits": w["bits"],
+                          "matches": M, "parallelism": "bucket ranges over %d rank(s)%s" % (
+                              world, ", exact-size all-gather-v of the pair lists" if gather else ", pair lists kept sharded"),
+                          "rank0_range": list(info["range"]), "rank0_tuples": [cr, cs], "pairs_per_rank": info["counts"]},
+               "roofline": {"bound": "hbm", "kernel": "probe kernel of rank 0's bucket range", "achieved": probe_bytes / (ms_probe * 1e-3) / 1e9 if ms_probe > 0 else 0.0,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (probe_bytes / (ms_probe * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_probe > 0 else 0.0,
+                            "traffic": None, "algorithmic_bytes": probe_bytes, "ms": ms_probe,
+                            "formula": "16*nS + 16*nR + 16*matches of the rank's range (SURVEY.md 8d)"}}
+        print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one independent join per rank (default); strong = ONE join sharded by bucket range "
+                         "over the ranks (sigmod-2018_amd/shard.py) with the exact-size all-gather-v of the pair lists")
+    ap.add_argument("--no-gather", action="store_true", help="strong scaling: keep the pair lists sharded (no exchange step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-hbm-table", action="store_true")
     args = ap.parse_args()
@@ -289,6 +378,11 @@ def main():
     if args.force_hbm_table:
         rhj.lib.rhj_set_force_hbm_table(1)
     dev = rhj.dev
+    if args.scaling == "strong":
+        run_strong(args, w, rhj, world, rank, backend, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     R, S = make_relations(w, dev, 1234 + rank)
     cap = w["nS"]
     out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
@@ -338,20 +432,23 @@ def main():
             return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
         part_ms = stage["ms_hist"] + stage["ms_scan"] + stage["ms_scatter"]
+        # SURVEY.md 8(d) with the ABI's AoS tuples: 16*n read by the histogram + 16*n read + 16*n written by the
+        # scatter = 48*n per relation, WHATEVER the number of passes the implementation takes (a second pass is
+        # this implementation's choice, not algorithmic work)
+        part_bytes = hist_bytes + scatter_bytes
+        part_formula = "48*n, both relations: 16*n histogram read + 16*n read + 16*n written by the scatter (SURVEY.md 8d, AoS)"
         if w["bits"] <= 8:        # one pass: per-tile histogram, scan, LDS-staged scatter
-            part_bytes = hist_bytes + scatter_bytes
             part = {"ms": part_ms, "GBps": gbs(part_bytes, part_ms), "algorithmic_bytes": part_bytes,
-                    "formula": "16*n read (histogram) + 16*n read + 16*n written (scatter), both relations",
+                    "formula": part_formula,
                     "histogram": {"ms": stage["ms_hist"], "GBps": gbs(hist_bytes, stage["ms_hist"])},
                     "scan": {"ms": stage["ms_scan"]},
                     "scatter": {"ms": stage["ms_scatter"], "GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
         else:                     # two passes in run form (k_local_part, k_hist_runs + scan, k_scatter_runs)
-            part_bytes = 2 * scatter_bytes
             part = {"ms": part_ms, "GBps": gbs(part_bytes, part_ms), "algorithmic_bytes": part_bytes,
-                    "formula": "2 passes x (16*n read + 16*n written), both relations",
-                    "pass1_tile_local": {"ms": stage["ms_hist"], "GBps": gbs(scatter_bytes, stage["ms_hist"])},
+                    "formula": part_formula,
+                    "pass1_tile_local": {"ms": stage["ms_hist"], "moved_GBps": gbs(scatter_bytes, stage["ms_hist"])},
                     "pass2_histogram_scan": {"ms": stage["ms_scan"]},
-                    "pass2_scatter_runs": {"ms": stage["ms_scatter"], "GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
+                    "pass2_scatter_runs": {"ms": stage["ms_scatter"], "moved_GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
         fused = stage["ms_count"] == 0.0 and stage["ms_probe"] > 0
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
         probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
@@ -391,6 +488,11 @@ def main():
                          "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"],
                          "formula": "16*nS + 16*nR + 16*matches (SURVEY.md 8d)"},
+            "roofline_partition": {"bound": "hbm", "kernel": "radix partition of both relations (all passes: tile-local pass, "
+                                   "pass-2 histogram + scans, run scatter)" if w["bits"] > 8 else "radix partition of both relations (histogram, scans, scatter)",
+                                   "achieved": gbs(part_bytes, part_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs(part_bytes, part_ms) / HBM_PEAK_GBS, "algorithmic_bytes": part_bytes, "ms": part_ms,
+                                   "formula": part_formula},
             "kernels": {
                 "probe_tuples_per_s_e9": nS / (stage["ms_probe"] * 1e-3) / 1e9 if stage["ms_probe"] > 0 else 0.0,
                 "join_phase_ms": join_ms,

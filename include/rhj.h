@@ -132,7 +132,8 @@ void rhj_set_empty_mode(int null_on_empty);
  * rhjoin.c:371 caps a 1 MiB node at 65535 pairs).  0 = one node for all. */
 void rhj_set_node_pairs(uint64_t pairs_per_node);
 /* Device ordinal (default 0 or env RHJ_DEVICE); must precede the first call. */
-int  rhj_set_device(int ordinal);
+int  rhj_set_device(int ordinal);       /* -1 once the context exists (one device per process) */
+int  rhj_get_device(void);
 /* Launch all work on this hipStream_t (passed as void*).  NULL is HIP's default stream (work the
  * caller queued there, e.g. through PyTorch's default stream, is then ordered before the join);
  * without this call the library uses a non-blocking stream of its own and the caller must have
@@ -192,12 +193,30 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out,
 int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n,
                       char op, uint64_t value, uint64_t *d_out, uint64_t *hits);
 
-/* Pin a host column store and keep a device copy (relation_map.c:39-50 layout:
- * the columns of one relation are contiguous, column-major).  Filter() uploads
- * lazily on first use when this was not called.  rhj_release() drops every
- * cached device buffer and the workspace. */
+/* Bucket-range sharding of ONE join over the GPUs of a node (bucket b of R only meets
+ * bucket b of S, rhjoin.c:42-57): the bucket histogram of a device-resident relation on the current
+ * radix bits (d_hist: 2^bits u64 on the device; what HistJob counts, preprocess.c:181-195), and the
+ * stable selection of the tuples whose bucket lies in [bucket_lo, bucket_hi) — input order and row ids
+ * kept, so rhj_join_device() of the selections is the canonical result restricted to that range and
+ * the concatenation over the ranks' ranges is the canonical result.  Returns 1 (and the count needed)
+ * when capacity was too small. */
+int rhj_bucket_histogram_device(const rhj_tuple *d_in, uint64_t n, uint64_t *d_hist);
+int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t bucket_lo, uint32_t bucket_hi,
+                                   rhj_tuple *d_out, uint64_t capacity, uint64_t *count);
+
+/* Register a host column store (relation_map.c:28-50 layout: the columns of one relation are one
+ * contiguous column-major block of the read-only file mapping): the block is pinned with
+ * hipHostRegister (read-only flag first; a range that cannot be pinned is copied pageable), every
+ * column is copied to the device once with hipMemcpyAsync, and Filter() and the resident operators
+ * read that copy until rhj_unregister_relation_map() (or rhj_release()) drops it.  The registry is
+ * the ONLY cache of host columns: a column that was not registered is uploaded on every call that
+ * names it, so reusing a host address for other data is always safe.  A caller must unregister a
+ * map before it frees or rewrites its columns. */
 int  rhj_register_relation_map(const rhj_relation_map *map, int num_relations);
-void rhj_release(void);
+int  rhj_unregister_relation_map(const rhj_relation_map *map, int num_relations);
+int  rhj_registered_columns(void);     /* registered columns / pinned host ranges right now */
+int  rhj_pinned_ranges(void);
+void rhj_release(void);                /* drops the registry, every device buffer and the workspace */
 
 const rhj_stats *rhj_last_stats(void);
 const char      *rhj_version(void);

@@ -25,9 +25,11 @@ PAIR = np.dtype([("row_idR", "<u8"), ("row_idS", "<u8")])     # structs.h:46-50
 ABI_SYMBOLS = [
     "RadixHashJoin", "Filter", "InsertResult", "InsertRowIdResult", "GetResultNum", "FindResultRowId",
     "FindResultTuples", "FreeResult", "PrintResult", "FreeRelation", "SchedulerInit", "SchedulerDestroy",
-    "rhj_set_radix_bits", "rhj_get_radix_bits", "rhj_set_empty_mode", "rhj_set_node_pairs", "rhj_set_device",
+    "rhj_set_radix_bits", "rhj_get_radix_bits", "rhj_set_empty_mode", "rhj_set_node_pairs", "rhj_set_device", "rhj_get_device",
     "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_join_device", "rhj_partition_device", "rhj_filter_device",
-    "rhj_register_relation_map", "rhj_release", "rhj_last_stats", "rhj_version",
+    "rhj_register_relation_map", "rhj_unregister_relation_map", "rhj_registered_columns", "rhj_pinned_ranges",
+    "rhj_bucket_histogram_device", "rhj_select_bucket_range_device",
+    "rhj_release", "rhj_last_stats", "rhj_version",
 ]
 # every symbol include/rhj_inter.h declares (device-resident intermediate results)
 INTER_SYMBOLS = [
@@ -127,6 +129,9 @@ def load_library(path=None):
     L.rhj_partition_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rhj_filter_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char, C.c_uint64, C.c_void_p, u64p]
     L.rhj_register_relation_map.argtypes = [C.POINTER(RelationMap), C.c_int]
+    L.rhj_unregister_relation_map.argtypes = [C.POINTER(RelationMap), C.c_int]
+    L.rhj_bucket_histogram_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.rhj_select_bucket_range_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
     L.rhj_last_stats.restype = C.POINTER(Stats)
     L.rhj_version.restype = C.c_char_p
     return L
@@ -146,7 +151,9 @@ class RHJ:
             raise RuntimeError("no GPU visible: the radix hash join has no CPU path")
         self.lib = load_library(lib_path)
         if device is not None:
-            self.lib.rhj_set_device(int(device))
+            if self.lib.rhj_set_device(int(device)) != 0 and self.lib.rhj_get_device() != int(device):
+                raise RuntimeError("librhj.so already runs on device %d: one library context per process "
+                                   "(rhj_set_device(%d) refused)" % (self.lib.rhj_get_device(), int(device)))
             torch.cuda.set_device(int(device))
         self.dev = torch.device("cuda", torch.cuda.current_device())
         if use_torch_stream:

@@ -5,6 +5,7 @@
 // There is no CPU fallback: any HIP failure is reported on stderr and returned as
 // an error; a missing GPU makes every entry point fail.
 #include "rhj_kernels.hip.h"
+#include "rhj_shard_kernels.hip.h"
 #include "rhj_internal.h"
 #include <mutex>
 
@@ -79,7 +80,13 @@ struct Ctx {
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_out[2] = {nullptr, nullptr};   // D2H staging of result pairs
     hipEvent_t ev_pin[2] = {};
-    std::map<std::pair<const void *, size_t>, void *> columns;   // host column -> device copy
+    // REGISTERED host columns (rhj_register_relation_map / the resident InitRelationMap) -> device copy.
+    // Nothing else is cached: an unregistered column is uploaded on every call that names it, so a caller
+    // that frees a column and gets the same address back never meets the old contents.
+    struct Column { void *dev; size_t rows; };
+    std::map<const void *, Column> columns;
+    std::map<const void *, size_t> pinned;                       // hipHostRegister'ed host ranges (base -> bytes)
+    Buf fcol;                                                    // staging of an unregistered column (host Filter())
     std::multimap<size_t, void *> free_blocks;                  // rhj_dev_alloc: cached blocks by size
     std::map<void *, size_t> live_blocks;                       // rhj_dev_alloc: blocks handed out
     rhj_stats stats = {};
@@ -117,7 +124,9 @@ int ensure(Buf &b, size_t bytes)
 
 int ctx_init()
 {
-    if (g.ready) return 0;
+    // HIP's current device is per thread: every entry point (all of them come through here under the API
+    // lock) selects the library's device on the calling thread before it allocates, records or launches
+    if (g.ready) { HIP_TRY(hipSetDevice(g.device)); return 0; }
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) { fprintf(stderr, "rhj: no HIP device visible; this library has no CPU path\n"); return -1; }
@@ -136,6 +145,7 @@ int ctx_init()
         for (const void *k : fused)
             HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     }
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
@@ -710,6 +720,7 @@ int rhj_set_device(int ordinal)
     g.device = ordinal;
     return 0;
 }
+int rhj_get_device(void) { return g.device; }
 void rhj_set_stream(void *s)
 {
     RhjApiLock api_lock;
@@ -783,17 +794,61 @@ int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, 
     return rc;
 }
 
+/* ---- bucket-range sharding of one join across GPUs (host side: sigmod-2018_amd/shard.py) ---- */
+
+int rhj_bucket_histogram_device(const rhj_tuple *d_in, uint64_t n, uint64_t *d_hist)
+{
+    RhjApiLock api_lock;
+    if (ctx_init()) return -1;
+    const int bits = g.bits;
+    HIP_TRY(hipMemsetAsync(d_hist, 0, ((size_t)8) << bits, g.stream));
+    if (n) {
+        uint64_t blocks = (n + SH_BLOCK * 16 - 1) / (SH_BLOCK * 16);
+        if (blocks > (uint64_t)g.cus * 4) blocks = (uint64_t)g.cus * 4;
+        RHJ_LAUNCH(k_bucket_hist, dim3((unsigned)blocks), dim3(SH_BLOCK), ((size_t)4) << bits, g.stream, d_in, n, bits,
+                   (unsigned long long *)d_hist);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t bucket_lo, uint32_t bucket_hi,
+                                   rhj_tuple *d_out, uint64_t capacity, uint64_t *count)
+{
+    RhjApiLock api_lock;
+    if (ctx_init()) return -1;
+    *count = 0;
+    if (n == 0 || bucket_hi <= bucket_lo) return 0;
+    const uint32_t mask = (1u << g.bits) - 1u;
+    const uint64_t tiles = (n + SH_TILE - 1) / SH_TILE;
+    if (ensure(g.ftile, tiles * 8) || ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary))) return -1;
+    uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
+    RHJ_LAUNCH(k_select_count, dim3((unsigned)tiles), dim3(SH_BLOCK), 0, g.stream, d_in, n, mask, bucket_lo, bucket_hi,
+               (uint64_t *)g.ftile.p);
+    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
+    RHJ_LAUNCH(k_select_write, dim3((unsigned)tiles), dim3(SH_BLOCK), 0, g.stream, d_in, n, mask, bucket_lo, bucket_hi,
+               (const uint64_t *)g.fbase.p, d_out, capacity);
+    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *count = *(uint64_t *)g.pin;
+    return *count > capacity ? 1 : 0;
+}
+
 void rhj_release(void)
 {
     RhjApiLock api_lock;
     if (!g.ready) return;
+    (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
                   &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
-                  &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
+                  &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
-    for (auto &kv : g.columns) (void)hipFree(kv.second);
+    for (auto &kv : g.columns) (void)hipFree(kv.second.dev);
     g.columns.clear();
+    for (auto &kv : g.pinned) (void)hipHostUnregister((void *)kv.first);
+    g.pinned.clear();
     for (auto &kv : g.free_blocks) (void)hipFree(kv.second);
     g.free_blocks.clear();
     for (auto &kv : g.live_blocks) (void)hipFree(kv.first);
@@ -868,30 +923,101 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
     return 0;
 }
 
-static void *column_device(const uint64_t *host_col, uint64_t rows)
+// The device copy of a registered column, or nullptr.
+static const uint64_t *registered_column(const uint64_t *host_col, uint64_t rows)
 {
-    auto key = std::make_pair((const void *)host_col, (size_t)rows);
-    auto it = g.columns.find(key);
-    if (it != g.columns.end()) return it->second;
+    auto it = g.columns.find((const void *)host_col);
+    if (it == g.columns.end() || it->second.rows != rows) return nullptr;
+    return (const uint64_t *)it->second.dev;
+}
+
+// Pin [base, base + bytes) for the H2D copy (relation_map.c:28-50: the columns of a relation are one
+// contiguous block of the PROT_READ | MAP_PRIVATE file mapping, hence the read-only flag first).
+// Returns whether the range is pinned now; a range that cannot be pinned is copied pageable.
+static bool pin_range(const void *base, size_t bytes)
+{
+    if (bytes < (64u << 10)) return false;                              // registration costs more than it saves
+    if (g.pinned.count(base)) return true;
+    hipError_t e = hipHostRegister((void *)base, bytes, hipHostRegisterReadOnly);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister((void *)base, bytes, hipHostRegisterDefault); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    g.pinned[base] = bytes;
+    return true;
+}
+
+static void unpin_range(const void *base)
+{
+    auto it = g.pinned.find(base);
+    if (it == g.pinned.end()) return;
+    (void)hipHostUnregister((void *)base);
+    g.pinned.erase(it);
+}
+
+static int register_column(const uint64_t *host_col, uint64_t rows)
+{
+    auto it = g.columns.find((const void *)host_col);
+    if (it != g.columns.end()) {
+        if (it->second.rows == rows) return 0;
+        (void)hipStreamSynchronize(g.stream);                           // registered again with another length: replace
+        (void)hipFree(it->second.dev);
+        g.columns.erase(it);
+    }
     void *d = nullptr;
-    if (hipMalloc(&d, (rows ? rows : 1) * 8) != hipSuccess) return nullptr;
-    if (hipMemcpyAsync(d, host_col, rows * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    g.columns[key] = d;
-    return d;
+    HIP_TRY(hipMalloc(&d, (rows ? rows : 1) * 8));
+    if (hipMemcpyAsync(d, host_col, rows * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) { (void)hipFree(d); return -1; }
+    g.columns[(const void *)host_col] = Ctx::Column{d, (size_t)rows};
+    return 0;
+}
+
+static void unregister_column(const uint64_t *host_col)
+{
+    auto it = g.columns.find((const void *)host_col);
+    if (it == g.columns.end()) return;
+    (void)hipFree(it->second.dev);
+    g.columns.erase(it);
+}
+
+// are the columns of this relation one contiguous block (the layout of relation_map.c:39-50)?
+static bool contiguous_columns(const rhj_relation_map *rm)
+{
+    for (uint64_t c = 1; c < rm->num_columns; ++c)
+        if (rm->columns[c] != rm->columns[c - 1] + rm->num_tuples) return false;
+    return rm->num_columns > 0;
 }
 
 int rhj_register_relation_map(const rhj_relation_map *map, int num_relations)
 {
     RhjApiLock api_lock;
     if (ctx_init()) return -1;
-    for (int r = 0; r < num_relations; ++r)
-        for (uint64_t c = 0; c < map[r].num_columns; ++c)
-            if (!column_device(map[r].columns[c], map[r].num_tuples)) return -1;
+    for (int r = 0; r < num_relations; ++r) {
+        const rhj_relation_map *rm = &map[r];
+        if (contiguous_columns(rm)) pin_range(rm->columns[0], (size_t)rm->num_columns * rm->num_tuples * 8);
+        else for (uint64_t c = 0; c < rm->num_columns; ++c) pin_range(rm->columns[c], (size_t)rm->num_tuples * 8);
+        for (uint64_t c = 0; c < rm->num_columns; ++c)
+            if (register_column(rm->columns[c], rm->num_tuples)) return -1;
+    }
     HIP_TRY(hipStreamSynchronize(g.stream));
     return 0;
 }
 
-// Filter on a host column (cached on the device after first use) with an optional
+int rhj_unregister_relation_map(const rhj_relation_map *map, int num_relations)
+{
+    RhjApiLock api_lock;
+    if (!g.ready) return 0;
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));                             // queued work may still read the device copies
+    for (int r = 0; r < num_relations; ++r)
+        for (uint64_t c = 0; c < map[r].num_columns; ++c) {
+            unregister_column(map[r].columns[c]);
+            unpin_range(map[r].columns[c]);
+        }
+    return 0;
+}
+
+int rhj_registered_columns(void) { return (int)g.columns.size(); }
+int rhj_pinned_ranges(void) { return (int)g.pinned.size(); }
+
+// Filter on a host column (its registered device copy, or uploaded for this call) with an optional
 // host row-id indirection vector; ids come back in `node_ids`-sized chunks.
 int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel, uint64_t n, char op, uint64_t value,
                     uint64_t *hits, void *(*alloc_chunk)(void *ctx, uint64_t ids), void *ctx, uint64_t node_ids)
@@ -901,8 +1027,12 @@ int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel,
     if (ctx_init()) return -1;
     if (op_code(op) < 0) return -3;
     if (n == 0) return 0;
-    const uint64_t *d_col = (const uint64_t *)column_device(col, col_rows);
-    if (!d_col) { fprintf(stderr, "rhj: cannot stage column on the device\n"); return -1; }
+    const uint64_t *d_col = registered_column(col, col_rows);
+    if (!d_col) {                                      // not registered: upload it for this call only
+        if (ensure(g.fcol, (col_rows ? col_rows : 1) * 8)) return -1;
+        HIP_TRY(hipMemcpyAsync(g.fcol.p, col, col_rows * 8, hipMemcpyHostToDevice, g.stream));
+        d_col = (const uint64_t *)g.fcol.p;
+    }
     const uint64_t *d_sel = nullptr;
     if (sel) {
         if (ensure(g.fcol_sel, n * 8)) return -1;
@@ -972,11 +1102,36 @@ void rhj_dev_free(void *p)
     g.live_blocks.erase(it);
 }
 void *rhj_dev_stream(void) { return ctx_init() ? nullptr : (void *)g.stream; }
-const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows)
+// Device copy of a host column for the resident operators: the registered copy, or — for a column nobody
+// registered — a fresh block uploaded now, returned in *temp for the caller to rhj_dev_free() once the
+// kernels that read it are queued (blocks are reused in stream order).
+const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows, void **temp)
 {
     RhjApiLock api_lock;
+    *temp = nullptr;
     if (ctx_init()) return nullptr;
-    return (const uint64_t *)column_device(host_col, rows);
+    if (const uint64_t *d = registered_column(host_col, rows)) return d;
+    void *blk = rhj_dev_alloc((rows ? rows : 1) * 8);
+    if (!blk) return nullptr;
+    if (hipMemcpyAsync(blk, host_col, rows * 8, hipMemcpyHostToDevice, g.stream) != hipSuccess) { rhj_dev_free(blk); return nullptr; }
+    *temp = blk;
+    return (const uint64_t *)blk;
+}
+int rhj_dev_register_column(const uint64_t *host_col, uint64_t rows, const void *pin_base, uint64_t pin_bytes)
+{
+    RhjApiLock api_lock;
+    if (ctx_init()) return -1;
+    if (pin_base) pin_range(pin_base, (size_t)pin_bytes);
+    return register_column(host_col, rows);
+}
+void rhj_dev_unregister_column(const uint64_t *host_col)
+{
+    RhjApiLock api_lock;
+    if (!g.ready) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    unregister_column(host_col);
+    unpin_range(host_col);
 }
 int rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out, uint64_t *matches)
 {

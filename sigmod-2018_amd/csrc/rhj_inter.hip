@@ -196,12 +196,22 @@ void gather(uint64_t *const *dst, const uint64_t *const *src, int ntab, const ui
     if (rhj_gather_tables_device(dst, src, ntab, idx, stride, n)) die("gather");
 }
 
-const uint64_t *column_of(const rhj_relation_map *rm, int column)
-{
-    const uint64_t *d = rhj_dev_column(rm->columns[column], rm->num_tuples);
-    if (!d) die("staging a column on the device");
-    return d;
-}
+// A column on the device for the duration of one operator: the registered copy (InitRelationMap,
+// rhj_register_relation_map) or, for a column nobody registered, an upload that is released when the
+// operator has queued its kernels.  Nothing is cached by host address.
+struct DevColumn {
+    const uint64_t *p;
+    void *temp;
+    DevColumn(const rhj_relation_map *rm, int column)
+    {
+        p = rhj_dev_column(rm->columns[column], rm->num_tuples, &temp);
+        if (!p) die("staging a column on the device");
+    }
+    ~DevColumn() { if (temp) rhj_dev_free(temp); }
+    DevColumn(const DevColumn &) = delete;
+    DevColumn &operator=(const DevColumn &) = delete;
+    operator const uint64_t *() const { return p; }
+};
 
 // the first node in which `rel` is active (inter_res.c:184-190, :243-249; filter.c:98-104)
 rhj_inter_res *node_of(rhj_inter_res *inter, int rel)
@@ -333,7 +343,7 @@ rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, 
         printf("Wrong comperator in filter function\n");
         exit(2);
     }
-    const uint64_t *col = column_of(rm, filter_p->column);       // filter.c:96
+    const DevColumn col(rm, filter_p->column);                   // filter.c:96
     rhj_inter_res *node = node_of(head, relation);               // filter.c:98-104
     const uint64_t *sel = node ? node->data->table[relation] : nullptr;
     const uint64_t n = node ? node->data->num_tuples : rm->num_tuples;
@@ -483,6 +493,7 @@ int InsertJoinToInterResults(rhj_inter_res *head, int rel1, int rel2, rhj_result
 
 rhj_relation *ScanInterResults(int given_rel, int column, rhj_inter_res *inter, rhj_relation_map *map, int *query_relations)
 {                                                               // inter_res.c:182-206
+    RhjApiLock api_lock;
     rhj_inter_res *node = node_of(inter, given_rel);
     if (node == nullptr) return nullptr;
     const rhj_relation_map *rm = &map[query_relations[given_rel]];
@@ -490,13 +501,14 @@ rhj_relation *ScanInterResults(int given_rel, int column, rhj_inter_res *inter, 
     rel->num_tuples = node->data->num_tuples;
     rel->tuples = (rhj_tuple *)rhj_dev_alloc(rel->num_tuples * sizeof(rhj_tuple));
     if (!rel->tuples) die("GetRelation");
-    if (rhj_build_relation_device(column_of(rm, column), node->data->table[given_rel], rel->num_tuples, rel->tuples)) die("GetRelation");
+    if (rhj_build_relation_device(DevColumn(rm, column), node->data->table[given_rel], rel->num_tuples, rel->tuples)) die("GetRelation");
     g_rel.insert(rel);
     return rel;
 }
 
 rhj_relation *GetRelation(int given_rel, int column, rhj_inter_res *inter, rhj_relation_map *map, int *query_relations)
 {                                                               // inter_res.c:208-231
+    RhjApiLock api_lock;
     rhj_relation *rel = nullptr;
     TRACE("GetRelation rel %d col %d", given_rel, column);
     if (inter != nullptr && (rel = ScanInterResults(given_rel, column, inter, map, query_relations)) != nullptr) return rel;
@@ -505,15 +517,16 @@ rhj_relation *GetRelation(int given_rel, int column, rhj_inter_res *inter, rhj_r
     rel->num_tuples = rm->num_tuples;
     rel->tuples = (rhj_tuple *)rhj_dev_alloc(rel->num_tuples * sizeof(rhj_tuple));
     if (!rel->tuples) die("GetRelation");
-    if (rhj_build_relation_device(column_of(rm, column), nullptr, rel->num_tuples, rel->tuples)) die("GetRelation");
+    if (rhj_build_relation_device(DevColumn(rm, column), nullptr, rel->num_tuples, rel->tuples)) die("GetRelation");
     g_rel.insert(rel);
     return rel;
 }
 
 rhj_result *SelfJoin(int given_rel, int column1, int column2, rhj_inter_res **inter, rhj_relation_map *map, int *query_relations)
 {                                                               // inter_res.c:234-263 (intended semantics, see rhj_inter.h)
+    RhjApiLock api_lock;
     const rhj_relation_map *rm = &map[query_relations[given_rel]];
-    const uint64_t *c1 = column_of(rm, column1), *c2 = column_of(rm, column2);
+    const DevColumn c1(rm, column1), c2(rm, column2);
     rhj_inter_res *node = node_of(*inter, given_rel);
     const uint64_t *sel = node ? node->data->table[given_rel] : nullptr;
     const uint64_t n = node ? node->data->num_tuples : rm->num_tuples;
@@ -581,7 +594,7 @@ void CalculateQueryResults(rhj_inter_res *inter, rhj_relation_map *map, rhj_batc
         const int relation = query->relations[index];
         const int column = query->views->data[i][2] - '0';
         uint64_t sum = 0;
-        if (rhj_sum_gather_device(column_of(&map[relation], column), inter->data->table[index], inter->data->num_tuples, &sum))
+        if (rhj_sum_gather_device(DevColumn(&map[relation], column), inter->data->table[index], inter->data->num_tuples, &sum))
             die("CalculateQueryResults");
         printf("%lu", (unsigned long)sum);
         if (i != query->views->num_of_elements - 1) printf(" ");
@@ -612,6 +625,7 @@ int AreActiveInInter(rhj_inter_res *inter, int rel1, int rel2)                  
 
 int JoinInterNode(rhj_inter_res **inter, rhj_relation_map *rel_map, int rel1, int col1, int rel2, int col2, int *relations)
 {                                                               // inter_res.c:363-389
+    RhjApiLock api_lock;
     rhj_inter_res *node = (*inter);
     while (node != nullptr) {
         if (node->data->table[rel1] != nullptr && node->data->table[rel2] != nullptr) break;
@@ -624,8 +638,8 @@ int JoinInterNode(rhj_inter_res **inter, rhj_relation_map *rel_map, int rel1, in
     trace_nodes(*inter);
     if (n != 0) {
         uint64_t *ids = alloc_ids(n), hits = 0;
-        if (rhj_filter_eq2_device(column_of(&rel_map[relations[rel1]], col1), node->data->table[rel1],
-                                  column_of(&rel_map[relations[rel2]], col2), node->data->table[rel2], n, ids, &hits))
+        const DevColumn cA(&rel_map[relations[rel1]], col1), cB(&rel_map[relations[rel2]], col2);
+        if (rhj_filter_eq2_device(cA, node->data->table[rel1], cB, node->data->table[rel2], n, ids, &hits))
             die("JoinInterNode");
         TRACE("JoinInterNode hits %lu", (unsigned long)hits);
         if (hits == 0) rhj_dev_free(ids);
@@ -762,8 +776,12 @@ int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)     
         for (uint64_t j = 0; j < rel_map[i].num_columns; ++j) {
             rel_map[i].columns[j] = map;
             map += rel_map[i].num_tuples;
-            // the device copy every later operator reads, and the statistics computed on it
-            const uint64_t *d_col = column_of(&rel_map[i], (int)j);
+            // the device copy every later operator reads (registered until FreeRelationMap; the relation's
+            // columns are one block of the file mapping, pinned for the copy), and the statistics computed on it
+            if (rhj_dev_register_column(rel_map[i].columns[j], rel_map[i].num_tuples, j == 0 ? (const void *)rel_map[i].columns[0] : nullptr,
+                                        rel_map[i].num_columns * rel_map[i].num_tuples * 8))
+                die("InitRelationMap");
+            const DevColumn d_col(&rel_map[i], (int)j);
             rhj_column_stats *st = &rel_map[i].col_stats[j];
             st->f = (double)rel_map[i].num_tuples;
             if (rhj_column_stats_device(d_col, rel_map[i].num_tuples, &st->l, &st->u, &st->d)) die("InitRelationMap");
@@ -779,6 +797,7 @@ void FreeRelationMap(rhj_relation_map *rel_map, int map_size)                   
 {
     RhjApiLock api_lock;
     for (int i = 0; i < map_size; ++i) {
+        for (uint64_t j = 0; j < rel_map[i].num_columns; ++j) rhj_dev_unregister_column(rel_map[i].columns[j]);
         free(rel_map[i].columns);
         free(rel_map[i].col_stats);
     }

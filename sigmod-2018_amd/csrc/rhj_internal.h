@@ -19,7 +19,11 @@ uint64_t rhj_host_node_pairs(void);
 void *rhj_dev_alloc(size_t bytes);                 /* stream-ordered, on the library's stream */
 void  rhj_dev_free(void *p);
 void *rhj_dev_stream(void);                        /* hipStream_t */
-const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows);   /* cached device copy of a host column */
+/* device copy of a host column: the REGISTERED copy (*temp = NULL), or a block uploaded for this call that the
+ * caller hands back with rhj_dev_free(*temp) once the kernels reading it are queued */
+const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows, void **temp);
+int   rhj_dev_register_column(const uint64_t *host_col, uint64_t rows, const void *pin_base, uint64_t pin_bytes);
+void  rhj_dev_unregister_column(const uint64_t *host_col);
 int   rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out,
                    uint64_t *matches);             /* *out is library-owned and valid until the next join */
 

@@ -1,0 +1,34 @@
+"""Stand-in for sigmod-2018_amd.shard.RhjOps where no GPU exists (CPU gloo tests): the same three device
+steps — bucket histogram, stable bucket-range selection, join — restated with numpy and the oracle on
+CPU tensors.  Test infrastructure only; the product's sharding code (shard.py) is what runs around it."""
+import numpy as np
+import torch
+
+from pyoracle import Oracle, TUPLE
+
+
+class OracleOps:
+    def __init__(self):
+        self.o = Oracle()
+        self.calls = {"histogram": 0, "select": 0, "join": 0}
+
+    def histogram(self, T, bits):
+        self.calls["histogram"] += 1
+        keys = T[:, 0].numpy().view(np.uint64)
+        return torch.from_numpy(np.bincount((keys & np.uint64((1 << bits) - 1)).astype(np.int64), minlength=1 << bits))
+
+    def select(self, T, bits, lo, hi, count):
+        self.calls["select"] += 1
+        b = T[:, 0] & ((1 << bits) - 1)
+        out = T[(b >= lo) & (b < hi)]
+        assert out.shape[0] == count
+        return out
+
+    def join(self, R, S, bits):
+        self.calls["join"] += 1
+        ra = np.ascontiguousarray(R.numpy()).view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
+        rb = np.ascontiguousarray(S.numpy()).view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
+        if len(ra) == 0 or len(rb) == 0:
+            return torch.empty((0, 2), dtype=torch.int64)
+        p = self.o.join(ra, rb, bits)
+        return torch.from_numpy(p.view(np.uint64).reshape(-1, 2).astype(np.int64))

@@ -268,6 +268,78 @@ def test_scripted_plans_match_the_reference_host_code(mod, rhj):
             e.L.FreeInterResults(e.head)
 
 
+def test_self_join_inactive_and_active_relation(mod, rhj):
+    """SelfJoin (inter_res.c:234-263) in its intended semantics (:252 reads map[given_rel]
+    instead of map[query_relations[given_rel]], :259 pushes a table pointer instead of the row position) against a
+    numpy statement of it: a relation that is not in the intermediate results yields its own row ids with
+    col1 == col2; one that is active yields the POSITIONS inside its node, as Filter does (filter.c:130), which is
+    what InsertSingleRowIdsToInterResult (filter.c:42-82) expects.  The reference's own code cannot be the
+    checker here (it reads the wrong relation and stores a pointer); small.work has no self-join predicate."""
+    lib = rhj.lib
+    P = C.POINTER
+    lib.SelfJoin.argtypes = [C.c_int, C.c_int, C.c_int, P(P(mod.InterRes)), P(mod.RelationMap), P(C.c_int)]
+    lib.SelfJoin.restype = P(mod.Result)
+    rng = np.random.default_rng(31)
+    rels = []
+    for rows, dom in ((5000, 7), (130_001, 5), (700, 3)):          # the middle one spans several filter tiles
+        rels.append([rng.integers(0, dom, rows, dtype=np.uint64) for _ in range(4)])
+    rels.append([np.arange(50, dtype=np.uint64), np.arange(50, dtype=np.uint64) + np.uint64(1)])   # never equal
+    rm, keep = make_map(mod, rels)
+    # query relations in a different order than the map, so that map[given_rel] != map[query_relations[given_rel]]
+    qrel = [2, 0, 1, 3]
+    q = (C.c_int * len(qrel))(*qrel)
+    e = Engine(mod, lib, rhj)
+    lib.InitInterResults(C.byref(e.head), len(qrel))
+
+    def ids_of(res):
+        n = lib.GetResultNum(res)
+        node = res.contents
+        assert not node.next, "one node per device-resident result"
+        return d2h(rhj, C.cast(node.buff, C.c_void_p).value, n)
+
+    # (a) not active: row ids of the mapped relation
+    for given in (1, 2):
+        cols = rels[qrel[given]]
+        res = lib.SelfJoin(given, 0, 1, C.byref(e.head), rm, q)
+        want = np.nonzero(cols[0] == cols[1])[0].astype(np.uint64)
+        assert bool(res) and np.array_equal(ids_of(res), want), given
+        if given == 2:
+            lib.InsertSingleRowIdsToInterResult(C.byref(e.head), given, res)
+            tab = want
+        lib.FreeResult(res)
+    assert np.array_equal(e.tables()[0][1][2], tab)
+    # (b) active (twice, so that the second one runs through a non-trivial position list)
+    for c1, c2 in ((2, 3), (1, 3)):
+        cols = rels[qrel[2]]
+        res = lib.SelfJoin(2, c1, c2, C.byref(e.head), rm, q)
+        pos = np.nonzero(cols[c1][tab] == cols[c2][tab])[0].astype(np.uint64)
+        assert bool(res) and np.array_equal(ids_of(res), pos), (c1, c2)
+        lib.InsertSingleRowIdsToInterResult(C.byref(e.head), 2, res)
+        lib.FreeResult(res)
+        tab = tab[pos]
+        (n, t), = e.tables()
+        assert n == len(tab) and sorted(t) == [2] and np.array_equal(t[2], tab)
+    # (c) a relation joined into the node (its table is a gathered row-id list, not a filter result)
+    relR = lib.GetRelation(2, 0, e.head, rm, q)
+    relS = lib.GetRelation(0, 0, e.head, rm, q)
+    res = lib.RadixHashJoin(relR, relS, None)
+    assert bool(res)
+    lib.InsertJoinToInterResults(e.head, 2, 0, res)
+    lib.FreeRelation(relR); lib.FreeRelation(relS); lib.FreeResult(res)
+    (n, t), = e.tables()
+    cols = rels[qrel[0]]
+    res = lib.SelfJoin(0, 1, 2, C.byref(e.head), rm, q)
+    pos = np.nonzero(cols[1][t[0]] == cols[2][t[0]])[0].astype(np.uint64)
+    assert bool(res) and np.array_equal(ids_of(res), pos)
+    lib.InsertSingleRowIdsToInterResult(C.byref(e.head), 0, res)
+    lib.FreeResult(res)
+    (n2, t2), = e.tables()
+    assert n2 == len(pos) and np.array_equal(t2[0], t[0][pos]) and np.array_equal(t2[2], t[2][pos])
+    # (d) no row with col1 == col2: NULL (query.c:383 prints NULL for the query)
+    assert not lib.SelfJoin(3, 0, 1, C.byref(e.head), rm, q)
+    lib.FreeInterResults(e.head)
+
+
 # ------------------------------------------------------------------ (3) relation loading and column statistics
 
 class ListNode(C.Structure):

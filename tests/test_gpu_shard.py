@@ -1,0 +1,118 @@
+"""GPU: the sharded join (sigmod-2018_amd/shard.py) with its device steps on the MI355X — RhjOps =
+rhj_bucket_histogram_device, rhj_select_bucket_range_device, rhj_join_device of librhj.so — and the
+exchange step over RCCL (backend "nccl"), at the world size this box offers (1 GPU under gpurun), checked
+bit for bit against the oracle.  The rank-count-dependent part (who takes which range, exact-size
+all-gather-v between peers) is covered at world_size 2 on gloo in tests/test_shard_gloo.py; here every
+RANGE of a 2-, 3- and 8-way split is additionally run on the one GPU and concatenated."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mod():
+    return importlib.import_module("sigmod-2018_amd")
+
+
+@pytest.fixture(scope="module")
+def rhj(mod):
+    return mod.RHJ()
+
+
+@pytest.fixture(scope="module")
+def shard():
+    return importlib.import_module("sigmod-2018_amd.shard")
+
+
+@pytest.fixture(scope="module")
+def nccl_world():
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    yield dist
+    dist.destroy_process_group()
+
+
+def relations(oracle, kind):
+    if kind == "zipf":
+        return oracle.generate(60000, 0, 0, 0.0, 42), oracle.generate(150000, 2, 60000, 0.9, 43)
+    R = oracle.generate(50000, 4, 3000, 0.0, 44)             # duplicates on both sides
+    S = oracle.generate(80000, 4, 3000, 0.0, 45)
+    R["value"] |= np.uint64(1) << np.uint64(63)              # top bit set: int64 views are negative
+    S["value"] |= np.uint64(1) << np.uint64(63)
+    R["row_id"] = R["row_id"][::-1].copy() + np.uint64(7)    # arbitrary row ids survive the selection
+    return R, S
+
+
+@pytest.mark.parametrize("kind", ["zipf", "dups_topbit"])
+@pytest.mark.parametrize("bits", [4, 8, 12])
+def test_sharded_join_on_the_device_under_nccl(rhj, shard, oracle, nccl_world, kind, bits):
+    ops = shard.RhjOps(rhj)
+    R, S = relations(oracle, kind)
+    dR, dS = rhj.to_device(R), rhj.to_device(S)
+    want = oracle.join(R, S, bits)
+    # the whole path at this box's world size: histogram, ranges, join, all-gather-v over RCCL
+    full, info = shard.sharded_join(ops, dR, dS, bits)
+    assert info["ranges"] == [(0, 1 << bits)] and info["counts"] == [len(want)]
+    assert np.array_equal(rhj.pairs_to_numpy(full), want)
+    # histogram against numpy
+    mask = np.uint64((1 << bits) - 1)
+    hr = np.bincount((R["value"] & mask).astype(np.int64), minlength=1 << bits)
+    hs = np.bincount((S["value"] & mask).astype(np.int64), minlength=1 << bits)
+    assert np.array_equal(ops.histogram(dR, bits).cpu().numpy(), hr)
+    assert np.array_equal(ops.histogram(dS, bits).cpu().numpy(), hs)
+    # every range of an N-way split through select + join on this GPU; concatenation = canonical order
+    for world in (2, 3, 8):
+        parts = []
+        for lo, hi in shard.bucket_ranges(hr, hs, world):
+            cr, cs = int(hr[lo:hi].sum()), int(hs[lo:hi].sum())
+            Rm, Sm = ops.select(dR, bits, lo, hi, cr), ops.select(dS, bits, lo, hi, cs)
+            sel = (R["value"] & mask >= np.uint64(lo)) & (R["value"] & mask < np.uint64(hi))
+            got = Rm.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got[:, 0], R["value"][sel]) and np.array_equal(got[:, 1], R["row_id"][sel])
+            parts.append(rhj.pairs_to_numpy(ops.join(Rm, Sm, bits)))
+        assert np.array_equal(np.concatenate(parts), want), (world, bits, kind)
+
+
+def test_allgatherv_and_independent_joins_on_device_tensors(rhj, shard, oracle, nccl_world):
+    import torch
+    ops = shard.RhjOps(rhj)
+    local = torch.arange(2 * 12345, dtype=torch.int64, device=rhj.dev).reshape(-1, 2)
+    full, counts = shard.allgatherv_pairs(local)
+    assert counts == [12345] and torch.equal(full, local)
+    empty, counts = shard.allgatherv_pairs(torch.empty((0, 2), dtype=torch.int64, device=rhj.dev))
+    assert counts == [0] and empty.shape == (0, 2)
+    rels = [(oracle.generate(n, 0, 0, 0.0, 50 + i), oracle.generate(m, 1, n, 0.0, 60 + i))
+            for i, (n, m) in enumerate(((9000, 20000), (300, 500), (5000, 5000)))]
+    joins = [(rhj.to_device(a), rhj.to_device(b)) for a, b in rels]
+    res, owner = shard.run_independent_joins(ops, joins, 8)
+    assert owner == [0, 0, 0]
+    for r, (a, b) in zip(res, rels):
+        assert np.array_equal(rhj.pairs_to_numpy(r), oracle.join(a, b, 8))
+
+
+def test_select_capacity_and_empty_ranges(rhj, oracle):
+    import ctypes as C
+    import torch
+    rhj.set_bits(6)
+    R = oracle.generate(10000, 1, 1000, 0.0, 9)
+    dR = rhj.to_device(R)
+    out = torch.empty((10000, 2), dtype=torch.int64, device=rhj.dev)
+    got = C.c_uint64(0)
+    lib = rhj.lib
+    assert lib.rhj_select_bucket_range_device(dR.data_ptr(), 10000, 5, 5, out.data_ptr(), 10000, C.byref(got)) == 0 and got.value == 0
+    assert lib.rhj_select_bucket_range_device(dR.data_ptr(), 10000, 0, 64, out.data_ptr(), 10000, C.byref(got)) == 0 and got.value == 10000
+    assert torch.equal(out, dR)
+    assert lib.rhj_select_bucket_range_device(dR.data_ptr(), 10000, 0, 64, out.data_ptr(), 100, C.byref(got)) == 1 and got.value == 10000
+    assert lib.rhj_select_bucket_range_device(dR.data_ptr(), 0, 0, 64, out.data_ptr(), 100, C.byref(got)) == 0 and got.value == 0

@@ -1,7 +1,8 @@
-"""CPU, world_size 2 over gloo: the multi-GPU sharding logic (bucket-range sharding of one
-join + all-gather-v of the pair lists; assignment of independent joins) reproduces the
-single-rank canonical result.  The per-rank join is the oracle here (the checker standing
-in for the device call, which needs a GPU); the sharding code is the product's."""
+"""CPU, world_size 2 over gloo: the product's multi-GPU sharding code (sigmod-2018_amd/shard.py:
+bucket-range sharding of one join + exact-size all-gather-v; independent joins of a plan dealt to ranks)
+reproduces the single-rank canonical result.  The three device steps (histogram, selection, join) are
+the oracle's here (tests/shard_ops.py) because this container has no GPU; tests/test_gpu_shard.py runs
+the very same functions with RhjOps = librhj.so on the device."""
 import importlib
 import os
 import socket
@@ -21,38 +22,49 @@ def _free_port():
     return p
 
 
+def _relations(o, bits):
+    R = o.generate(40000, 0, 0, 0.0, 42)
+    S = o.generate(70000, 2, 40000, 0.9, 43)          # Zipf: unbalanced buckets
+    return R, S
+
+
 def _worker(rank, world, port, bits, out_q):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     import torch
     import torch.distributed as dist
-    from pyoracle import Oracle, TUPLE, PAIR
+    from pyoracle import Oracle, PAIR
+    from shard_ops import OracleOps
     shard = importlib.import_module("sigmod-2018_amd.shard")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     o = Oracle()
-    R = o.generate(40000, 0, 0, 0.0, 42)
-    S = o.generate(70000, 2, 40000, 0.9, 43)          # Zipf: unbalanced buckets
+    ops = OracleOps()
+    R, S = _relations(o, bits)
     tR = torch.from_numpy(R.view(np.int64).reshape(-1, 2).copy())
     tS = torch.from_numpy(S.view(np.int64).reshape(-1, 2).copy())
 
-    def join_fn(a, b):
-        ra = np.ascontiguousarray(a.numpy()).view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
-        rb = np.ascontiguousarray(b.numpy()).view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
-        p = o.join(ra, rb, bits)
-        return torch.from_numpy(p.view(np.uint64).reshape(-1, 2).astype(np.int64))
+    def as_pairs(t):
+        return t.numpy().view(np.uint64).reshape(-1, 2).copy().view(PAIR).reshape(-1)
 
-    mask = (1 << bits) - 1
-    hr = np.bincount((R["value"] & np.uint64(mask)).astype(np.int64), minlength=1 << bits)
-    hs = np.bincount((S["value"] & np.uint64(mask)).astype(np.int64), minlength=1 << bits)
-    lo, hi = shard.bucket_ranges(hr, hs, world)[rank]
-    local = shard.join_bucket_range(tR, tS, bits, lo, hi, join_fn)
-    full, counts = shard.allgatherv_pairs(local)
+    # (1) one join sharded by bucket range, pair lists exchanged
+    full, info = shard.sharded_join(ops, tR, tS, bits)
     want = o.join(R, S, bits)
-    got = full.numpy().view(np.uint64).reshape(-1, 2).copy().view(PAIR).reshape(-1)
-    ok = len(got) == len(want) and bool((got == want).all()) and sum(counts) == len(want)
-    out_q.put((rank, ok, counts, (lo, hi)))
+    got = as_pairs(full)
+    ok1 = len(got) == len(want) and bool((got == want).all()) and sum(info["counts"]) == len(want)
+    ok1 = ok1 and ops.calls == {"histogram": 2, "select": 2, "join": 1}
+    # (2) kept sharded (the consumer lives on this rank): this rank's slice only
+    local, info2 = shard.sharded_join(ops, tR, tS, bits, gather=False)
+    off = sum(info["counts"][:rank])
+    ok2 = bool((as_pairs(local) == want[off:off + info["counts"][rank]]).all())
+    # (3) independent joins of a plan: three joins of different size, gathered everywhere
+    rels = [(o.generate(n, 0, 0, 0.0, 50 + i), o.generate(m, 1, n, 0.0, 60 + i)) for i, (n, m) in enumerate(((9000, 20000), (300, 500), (5000, 5000)))]
+    tj = [(torch.from_numpy(a.view(np.int64).reshape(-1, 2).copy()), torch.from_numpy(b.view(np.int64).reshape(-1, 2).copy())) for a, b in rels]
+    res, owner = shard.run_independent_joins(ops, tj, bits)
+    ok3 = all(bool((as_pairs(r) == o.join(a, b, bits)).all()) for r, (a, b) in zip(res, rels))
+    ok3 = ok3 and owner[0] != owner[2] and len(set(owner)) == 2
+    out_q.put((rank, ok1 and ok2 and ok3, info["counts"], info["range"], (ok1, ok2, ok3)))
     dist.destroy_process_group()
 
 
