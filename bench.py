@@ -449,17 +449,22 @@ def main():
                     "pass1_tile_local": {"ms": stage["ms_hist"], "moved_GBps": gbs(scatter_bytes, stage["ms_hist"])},
                     "pass2_histogram_scan": {"ms": stage["ms_scan"]},
                     "pass2_scatter_runs": {"ms": stage["ms_scatter"], "moved_GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
-        fused = stage["ms_count"] == 0.0 and stage["ms_probe"] > 0
+        fused = st["path"] == "fused"
+        sub = st["path"] == "subsplit"
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
         probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
+                        else "k_sub_join + k_sub_bscan + k_sub_emit (LDS-resident sub-bucket join, bucket offsets, canonical emit: the whole probe phase)" if sub
                         else "k_probe<WRITE> (emit pass of the tiled path)")
+        if sub:                   # the probe phase is two kernels and a scan: the roofline is stated on their sum
+            stage["ms_probe_emit"] = stage["ms_probe"]
+            stage["ms_probe"] = join_ms
         # HBM-side bytes of the dominant kernel per launch: rocprofv3 --pmc passes of this same command,
         # committed under profiles/ (tools/pmc.sh; counters cannot be read from inside this process)
         traffic, traffic_src = None, None
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_%s_pmc.json" % args.workload)))
-            if cands and fused:
+            if cands and (fused or sub):
                 pm = json.load(open(cands[-1]))
                 for kname, kv in pm.items():
                     if "k_join_fused" in kname and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
@@ -482,7 +487,8 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": w["name"], "id": args.workload, "nR": nR, "nS": nS, "radix_bits": w["bits"],
                        "matches": M, "parallelism": "independent join per GPU" if world > 1 else "1 GPU",
-                       "path": "fused" if fused else "tiled", "units": st["units"], "max_build_side": st["max_build"]},
+                       "path": st["path"], "sub_bits": st["sub_bits"], "pass1_bits": st["pass1_bits"],
+                       "units": st["units"], "max_build_side": st["max_build"]},
             "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -501,6 +507,8 @@ def main():
                 "plan": {"ms": stage["ms_plan"]},
                 "build_tables": {"ms": stage["ms_build"]}, "count": {"ms": stage["ms_count"]},
                 "offsets": {"ms": stage["ms_offsets"]},
+                "subsplit": ({"k_sub_join_ms": stage["ms_build"], "k_sub_bscan_ms": stage["ms_offsets"],
+                              "k_sub_emit_ms": stage.get("ms_probe_emit", 0.0)} if sub else None),
                 "gpu_total_ms": stage["ms_total"],
             },
         }
