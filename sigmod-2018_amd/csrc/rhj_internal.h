@@ -12,6 +12,7 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
 int rhj_host_filter(const uint64_t *col, uint64_t col_rows, const uint64_t *sel, uint64_t n, char op,
                     uint64_t value, uint64_t *hits, void *(*alloc_chunk)(void *ctx, uint64_t ids), void *ctx,
                     uint64_t node_ids);
+void rhj_host_pool_release(void);                  /* rhj_abi.c: parked result-node buffers */
 int rhj_host_null_on_empty(void);
 uint64_t rhj_host_node_pairs(void);
 

@@ -596,14 +596,25 @@ __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, 
     }
 }
 
-template <bool T12>                                   // (a run-time switch here cost 30 %: compiled apart, both launched)
-__global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
+// T12: 12-byte intermediates in; O12: 12-byte tuples out too (the join's own partition when the row ids fit 32 bits:
+// the fused kernel then streams and gathers 12 instead of 16 bytes per tuple; rhj_partition_device() hands out
+// rhj_tuple and keeps 16-byte output).  (A run-time switch here cost 30 %: compiled apart, launched side by side.)
+#ifndef SR_VN
+#define SR_VN 8         // tuples per thread and batch of pass 2 (the batch is independent of pass 1's 4096-tuple tiles)
+#endif
+#ifndef SR_MINW
+#define SR_MINW 4
+#endif
+constexpr int SR_V = SR_VN;
+constexpr int SR_TILE = PT_BLOCK * SR_V;
+template <bool T12, bool O12>
+__global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
                                                            const PlanSummary *summary)
 {
     if ((summary->wide_row_ids == 0) != T12) return;      // the other instantiation's launch moves the data
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [SR_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)SR_TILE * 16); // [PT_WAVES][bins]
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
     uint32_t *delta = dstart + bins;                                           // [bins]
@@ -655,16 +666,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
     }
     __syncthreads();
 
-    for (uint32_t sb = 0; sb < total; sb += PT_TILE) {
-        const uint32_t count = min((uint32_t)PT_TILE, total - sb);
+    for (uint32_t sb = 0; sb < total; sb += SR_TILE) {
+        const uint32_t count = min((uint32_t)SR_TILE, total - sb);
         for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
 
-        uint4 t[PT_V];
-        bool ok[PT_V];
+        uint4 t[SR_V];
+        bool ok[SR_V];
         uint32_t pos = 0;                             // last run that starts at or before the element
 #pragma unroll
-        for (int k = 0; k < PT_V; ++k) {
-            const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
+        for (int k = 0; k < SR_V; ++k) {
+            const uint32_t i = w * (WAVE * SR_V) + k * WAVE + lane;
             ok[k] = i < count;
             const uint32_t e = sb + i;
             if (k == 0) {
@@ -687,10 +698,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
         }
         __syncthreads();
 
-        uint32_t lrank[PT_V], dig[PT_V];
+        uint32_t lrank[SR_V], dig[SR_V];
         uint32_t *mycnt = wcnt + w * bins;
 #pragma unroll
-        for (int k = 0; k < PT_V; ++k) {
+        for (int k = 0; k < SR_V; ++k) {
             const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;
             const uint32_t d = (uint32_t)(key >> shift) & mask;
             dig[k] = d;
@@ -727,17 +738,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_runs(RelArgs r0, RelArgs r
         __syncthreads();
 
 #pragma unroll
-        for (int k = 0; k < PT_V; ++k)
+        for (int k = 0; k < SR_V; ++k)
             if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
         __syncthreads();
 
 #pragma unroll
-        for (int k = 0; k < PT_V; ++k) {
+        for (int k = 0; k < SR_V; ++k) {
             const uint32_t p = k * PT_BLOCK + threadIdx.x;
             if (p < count) {
                 const uint4 v = stage[p];
                 const uint32_t d = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> shift) & mask;
-                out[delta[d] + p] = v;
+                if (O12) reinterpret_cast<Tuple12 *>(r.out)[delta[d] + p] = Tuple12{v.x, v.y, v.z};
+                else out[delta[d] + p] = v;
             }
         }
         __syncthreads();
@@ -1302,6 +1314,19 @@ struct FjIndex {
 };
 __device__ __forceinline__ uint32_t fj_tag(uint64_t h) { return min((uint32_t)(h >> 16) & 0xffffu, 0xfffdu) + 1u; }
 
+// Partitioned relations as the fused kernel sees them: rhj_tuple (16 B), or — N32: the partition found every row id
+// below 2^32 and wrote Tuple12 — 12 bytes per tuple.  Whole tuple as {key lo, key hi, row id lo, row id hi}.
+template <bool N32> __device__ __forceinline__ uint4 pt_load(const rhj_tuple *base, uint64_t i)
+{
+    if (N32) { const Tuple12 x = reinterpret_cast<const Tuple12 *>(base)[i]; return make_uint4(x.klo, x.khi, x.rid, 0u); }
+    return reinterpret_cast<const uint4 *>(base)[i];
+}
+template <bool N32> __device__ __forceinline__ uint2 pt_load_key(const rhj_tuple *base, uint64_t i)
+{
+    if (N32) { const Tuple12 *x = reinterpret_cast<const Tuple12 *>(base) + i; return make_uint2(x->klo, x->khi); }
+    return reinterpret_cast<const uint2 *>(base)[2 * i];
+}
+
 // hit mask of the first min(n, 8) entries of the window at `start`
 __device__ __forceinline__ uint32_t fj_window(const FjIndex &X, uint32_t start, uint32_t n, uint32_t tgs)
 {
@@ -1371,12 +1396,11 @@ __device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V],
 // for the cooperative sort of long slots.
 constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
 constexpr int FJ_SMALL = 4;                           // batches of 4096 build tuples whose (slot, tag) words are kept for the fill pass
-template <bool RES>
-__device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, uint32_t bc, uint4 *ltup,
+template <bool RES, bool N32>
+__device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *part, uint64_t boff, uint32_t bc, uint4 *ltup,
                                          uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint4 *bd4 = reinterpret_cast<const uint4 *>(bd);
     const uint32_t ndw = (X.hs + 3u) / 2u;
     for (uint32_t i = tid; i < ndw; i += FJ_BLOCK) X.dirw[i] = 0;
     for (uint32_t i = tid; i < bc; i += FJ_BLOCK) X.ent[i] = 0;
@@ -1392,14 +1416,14 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = k * FJ_BLOCK + tid;
             t[k] = make_uint4(0, 0, 0, 0);
-            if (i < bc) { if (RES) t[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; t[k].x = kv.x; t[k].y = kv.y; } }
+            if (i < bc) { if (RES) t[k] = pt_load<N32>(part, boff + i); else { const uint2 kv = pt_load_key<N32>(part, boff + i); t[k].x = kv.x; t[k].y = kv.y; } }
         }
         for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {               // next batch's loads fly while this batch is counted
                 const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + tid;
                 tn[k] = make_uint4(0, 0, 0, 0);
-                if (i < bc) { if (RES) tn[k] = bd4[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; tn[k].x = kv.x; tn[k].y = kv.y; } }
+                if (i < bc) { if (RES) tn[k] = pt_load<N32>(part, boff + i); else { const uint2 kv = pt_load_key<N32>(part, boff + i); tn[k].x = kv.x; tn[k].y = kv.y; } }
             }
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
@@ -1488,14 +1512,14 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = k * FJ_BLOCK + tid;
             t[k] = make_uint4(0, 0, 0, 0);
-            if (i < bc) { if (RES) t[k] = ltup[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; t[k].x = kv.x; t[k].y = kv.y; } }
+            if (i < bc) { if (RES) t[k] = ltup[i]; else { const uint2 kv = pt_load_key<N32>(part, boff + i); t[k].x = kv.x; t[k].y = kv.y; } }
         }
         for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
                 const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + tid;
                 tn[k] = make_uint4(0, 0, 0, 0);
-                if (i < bc) { if (RES) tn[k] = ltup[i]; else { const uint2 kv = reinterpret_cast<const uint2 *>(bd)[2 * (size_t)i]; tn[k].x = kv.x; tn[k].y = kv.y; } }
+                if (i < bc) { if (RES) tn[k] = ltup[i]; else { const uint2 kv = pt_load_key<N32>(part, boff + i); tn[k].x = kv.x; tn[k].y = kv.y; } }
             }
 #pragma unroll
             for (int k = 0; k < FJ_V; ++k) {
@@ -1542,18 +1566,25 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *bd, 
 // sc1 (L1 bypass): a gathered line is used once per candidate, so allocating it in the 32 KiB
 // vector L1 only evicts the streamed probe data.  A/B on MI355X (tools/ab.py, fused kernel on
 // 100Mx100M@12): plain 4.64 ms, nt 4.06 ms, sc1 3.8 ms.
+template <bool N32>
 struct FjGather {
     __amdgpu_buffer_rsrc_t rsrc;
-    __device__ __forceinline__ void init(const rhj_tuple *bd, uint32_t bc)
+    static constexpr uint32_t STRIDE = N32 ? 12u : 16u;
+    __device__ __forceinline__ void init(const rhj_tuple *part, uint64_t boff, uint32_t bc)
     {
-        const uint64_t addr = (uint64_t)bd;                       // wave-uniform by construction: make it provable
+        const uint64_t addr = (uint64_t)part + boff * STRIDE;     // wave-uniform by construction: make it provable
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
-        const uint32_t bytes = __builtin_amdgcn_readfirstlane(bc * 16u);
+        const uint32_t bytes = __builtin_amdgcn_readfirstlane(bc * STRIDE);
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
     }
     __device__ __forceinline__ uint4 load(uint32_t pos) const
     {
+        if (N32) {
+            typedef uint32_t v3 __attribute__((ext_vector_type(3)));
+            const v3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(pos * 12u), 0, 16 /* sc1 */);
+            return make_uint4(v.x, v.y, v.z, 0u);
+        }
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, 16 /* sc1 */);
         return make_uint4(v.x, v.y, v.z, v.w);
@@ -1575,8 +1606,8 @@ struct FjOvf {
     uint32_t  gid;        // group of this wave in this batch
 };
 
-template <bool RES, bool OVF>
-__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather &G, const uint4 *ltup,
+template <bool RES, bool OVF, bool N32>
+__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather<N32> &G, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
                                                uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
                                                const FjOvf &O)
@@ -1833,8 +1864,9 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     const uint64_t cR = a.histR[b], cS = a.histS[b];
     const bool flip = cR < cS;                                         // S is streamed (r_s == 1)
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;   // position in the probe relation
-    const rhj_tuple *pr = (flip ? a.partS : a.partR) + ppos;
-    const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
+    const rhj_tuple *prp = flip ? a.partS : a.partR;                   // probe tuple i of the unit: pt_load<N32>(prp, ppos + i)
+    const rhj_tuple *bdp = flip ? a.partR : a.partS;                   // build tuple i of the bucket: pt_load<N32>(bdp, bpos + i)
+    const uint64_t bpos = flip ? a.psumR[b] : a.psumS[b];
     const uint32_t bc = (uint32_t)(flip ? cR : cS);
     // LDS: [resident build tuples 16 B x bc] [entries 4 B x (bc + 8)] [slot starts 2 B x (hs + 1)]
     const uint32_t bcp = (bc + 3u) & ~3u;
@@ -1854,9 +1886,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     X.dirw = X.ent + bcp + 8u;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
     uint2 *srow = reinterpret_cast<uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
-    const uint4 *pr4 = reinterpret_cast<const uint4 *>(pr);
-    FjGather G;
-    G.init(bd, bc);
+    FjGather<N32> G;
+    G.init(bdp, bpos, bc);
     FjOvf O;                                          // double-buffered: the previous unit's emit may still be pending
     O.buf = f.ovf + ((size_t)blockIdx.x * 2 + (iter & 1u)) * FJ_OVF_CAP;
     O.table = f.ovf_base + ((size_t)blockIdx.x * 2 + (iter & 1u)) * (FJ_GROUPS * 16u);
@@ -1865,8 +1896,8 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 
     if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
-    if (RES) fj_build<true>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
-    else     fj_build<false>(X, bd, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
+    if (RES) fj_build<true, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
+    else     fj_build<false, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
     if (FJ_ABLATE == 1) continue;                      // timing experiment: build only
     if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
@@ -1890,11 +1921,11 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + k * WAVE + lane;
             okk[k] = i < un.count;
-            q[k] = okk[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+            q[k] = okk[k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
         }
         O.gid = grp;
-        if (RES) fj_count_batch<true, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
-        else     fj_count_batch<false, true>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        if (RES) fj_count_batch<true, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + k * WAVE + lane;
@@ -1989,7 +2020,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                 const uint32_t i = t0 + w * (WAVE * FJ_V * FJ_H) + h * (WAVE * FJ_V) + k * WAVE + lane;
                 okk[h][k] = i < un.count;
                 fpt[h][k] = false;
-                q[h][k] = okk[h][k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+                q[h][k] = okk[h][k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
                 const uint32_t sb = okk[h][k] ? scnt[i] : 0;
                 c[h][k] = sb & 0x7fu;
                 fpt[h][k] = (sb & 0x80u) != 0;
@@ -2304,8 +2335,8 @@ __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t
 __global__ __launch_bounds__(FJ_BLOCK) void k_gather_bench(const rhj_tuple *base, uint32_t region_elems, uint32_t rounds,
                                                            const uint4 *stream, uint32_t stream_per_round, uint4 *sink)
 {
-    FjGather G;
-    G.init(base + (size_t)blockIdx.x * region_elems, region_elems);
+    FjGather<false> G;
+    G.init(base, (uint64_t)blockIdx.x * region_elems, region_elems);
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 1u;
     uint4 acc = make_uint4(0, 0, 0, 0);
     const uint4 *sp = stream + ((size_t)blockIdx.x * rounds) * stream_per_round * FJ_BLOCK + threadIdx.x;
