@@ -176,6 +176,8 @@ struct PartState {
     RelArgs  r[2];           // in = caller's input, out = final partitioned array
     rhj_tuple *tmp[2];       // intermediate of the two-pass path
     uint64_t *hist, *psum;   // [2][bins] of the join's radix (filled by run_partition)
+    const PlanArgs *plan = nullptr;   // the join's plan arguments: a small one-pass partition runs the plan in its scan launch
+    bool plan_done = false;
 };
 
 uint32_t tiles_for(uint64_t n)
@@ -197,11 +199,24 @@ size_t scatter_runs_lds_bytes(int bits)
 }
 
 // one stable pass over both relations (radix bits <= 8): per-tile histogram, scan, LDS-staged scatter
-int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, uint64_t *psum)
+int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, uint64_t *psum, const PlanArgs *plan = nullptr,
+                   bool *plan_done = nullptr)
 {
     const uint32_t bins = 1u << bits;
     uint32_t max_tiles = r0.tiles;
     if (nrel > 1 && r1.tiles > max_tiles) max_tiles = r1.tiles;
+    if (plan && nrel == 2 && max_tiles <= SMALL_TILES) {
+        // small join: histogram, {scans + plan} in one single-workgroup launch, scatter — three launches instead of seven
+        HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+        RHJ_LAUNCH(k_hist_tiles, dim3(max_tiles, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
+        HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+        RHJ_LAUNCH(k_small_scan_plan, dim3(1), dim3(1024), 0, g.stream, r0, r1, bits, hist, psum, *plan);
+        HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+        RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
+        HIP_TRY(hipGetLastError());
+        *plan_done = true;
+        return 0;
+    }
     uint32_t chunks = (max_tiles + 15) / 16;                  // >= 16 tiles per chunk, at most 512 chunks
     if (chunks > 512) chunks = 512;
     if (chunks < 1) chunks = 1;
@@ -251,7 +266,7 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     if (bits <= PT_MAX_BITS) {
         // one pass: no 12-byte intermediates and nothing that checks the row ids, so everything downstream stays wide
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&((PlanSummary *)g.summary.p)->wide_row_ids, 1, 1, g.stream));
-        return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, bits, ps.hist, ps.psum);
+        return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, bits, ps.hist, ps.psum, ps.plan, &ps.plan_done);
     }
 
     // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
@@ -394,13 +409,9 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         if (ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple))) return -1;
         ps.tmp[0] = (rhj_tuple *)g.tmpR.p; ps.tmp[1] = (rhj_tuple *)g.tmpS.p;
     }
-    // the fused path reads 12-byte partitioned tuples when the row ids fit 32 bits; the tiled path reads rhj_tuple
-    const bool want_fused = !g.no_fused && !g.force_hbm;
-    if (!want_fused) force_wide = true;
-    if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
-
-    // ---- plan
+    // ---- plan arguments (the plan runs behind the partition; a small one-pass partition runs it in its scan launch)
     const uint32_t build_chunk = 4096;
+    const bool want_fused = !g.no_fused && !g.force_hbm;
     const uint32_t lds_max_slots = LDS_BUDGET / 4 / 4 * 4;                 // tiled path: k_build_lds owns the whole LDS
     uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
     if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 128) * 2 / 9;   // fused: 4 B entry + >= 0.5 B of slot starts per build tuple
@@ -412,11 +423,11 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     const uint64_t max_tab32 = nmin + nmin / 2 + (uint64_t)80 * bins + 64;
     if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) ||
         ensure(g.ldsb, (size_t)bins * 4) || ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) ||
-        ensure(g.summary, sizeof(PlanSummary)) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
-        ensure(g.uflag, max_units * 4))
+        ensure(g.summary, sizeof(PlanSummary) + sizeof(SjSummary)) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
+        ensure(g.uflag, max_units * 4) || ensure(g.histpsum, (size_t)4 * bins * 8))
         return -1;
     PlanArgs pa;
-    pa.histR = ps.hist; pa.histS = ps.hist + bins;
+    pa.histR = (uint64_t *)g.histpsum.p; pa.histS = pa.histR + bins;
     pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk;
@@ -429,8 +440,14 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         if (want < fused_span) fused_span = (uint32_t)want;
     }
     pa.span_lds = want_fused ? fused_span : PR_UNIT;
+
+    // the fused path reads 12-byte partitioned tuples when the row ids fit 32 bits; the tiled path reads rhj_tuple
+    if (!want_fused) force_wide = true;
+    ps.plan = &pa;
+    if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
+
     HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
-    RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+    if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     PlanSummary *hs = (PlanSummary *)g.pin;
     PlanSummary plan;
 

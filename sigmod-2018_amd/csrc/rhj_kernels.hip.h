@@ -784,10 +784,8 @@ __device__ __forceinline__ uint32_t lds_slots_for(uint64_t bc, uint32_t max_slot
     return min(max(s, 64u), max_slots);
 }
 
-__global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
+__device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t *sm /*1024 / 64 + 1*/, unsigned long long *red /*2*/)
 {
-    __shared__ uint64_t sm[1024 / 64 + 1];
-    __shared__ unsigned long long red[2];
     const uint32_t bins = 1u << bits;
     const uint32_t per = (bins + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, bins);
@@ -859,6 +857,66 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
         s.wide_row_ids = a.summary->wide_row_ids; s.row_id_overflow = a.summary->row_id_overflow;     // the partition's words
         *a.summary = s;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
+{
+    __shared__ uint64_t sm[1024 / 64 + 1];
+    __shared__ unsigned long long red[2];
+    plan_body(a, bits, sm, red);
+}
+
+// Small joins (one-pass partition, at most SMALL_TILES tiles per relation: 1M x 1M has 245): the four scan kernels of
+// the partition and the plan in ONE single-workgroup launch — such a join is bound by its launches, not by its bytes.
+// Per relation: thread (slice, digit) sums its slice of the tiles' counts, the digits' totals are scanned, and the
+// same thread turns its counts into start offsets in place; then the plan over the two histograms.
+constexpr uint32_t SMALL_TILES = 1024;
+__global__ __launch_bounds__(1024) void k_small_scan_plan(RelArgs r0, RelArgs r1, int bits, uint64_t *hist, uint64_t *psum, PlanArgs a)
+{
+    __shared__ uint64_t sm[1024 / 64 + 1];
+    __shared__ unsigned long long red[2];
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t base_sh[2][256];
+    const uint32_t bins = 1u << bits;
+    // threads 0..511 take R, 512..1023 S: thread (slice, digit) of its half
+    const uint32_t rel = threadIdx.x >> 9, t = threadIdx.x & 511u;
+    const RelArgs &r = rel ? r1 : r0;
+    const uint32_t d = t & (bins - 1u), slice = t >> bits, slices = 512u >> bits;
+    const uint32_t per = (r.tiles + slices - 1u) / slices;
+    const uint32_t t0 = min(slice * per, r.tiles), t1 = min(t0 + per, r.tiles);
+    uint32_t *col = r.cnt + d;
+    uint32_t acc = 0;
+#pragma unroll 16
+    for (uint32_t i = t0; i < t1; ++i) acc += col[(size_t)i * bins];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    uint64_t tot = 0;                                 // threads 0..bins-1: R's digits, 512..512+bins-1: S's
+    if (t < bins)
+        for (uint32_t q = 0; q < slices; ++q) tot += part[rel * 512u + q * bins + t];
+    // one scan over both halves: S's digits sit behind R's, so take R's total off again
+    uint64_t all;
+    const uint64_t ex = block_excl_scan<1024>(tot, &all, sm);
+    if (t < bins) {
+        const uint64_t e = rel ? ex - r0.n : ex;      // exclusive prefix inside S = prefix over both - all of R
+        hist[(size_t)rel * bins + t] = tot;
+        psum[(size_t)rel * bins + t] = e;
+        base_sh[rel][t] = (uint32_t)e;
+    }
+    __syncthreads();
+    uint32_t run = base_sh[rel][d];
+    for (uint32_t q = 0; q < slice; ++q) run += part[rel * 512u + q * bins + d];
+    uint32_t c[16];
+    for (uint32_t i0 = t0; i0 < t1; i0 += 16) {       // sixteen loads in flight, then their stores
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[j] = i0 + j < t1 ? col[(size_t)(i0 + j) * bins] : 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (i0 + j < t1) col[(size_t)(i0 + j) * bins] = run;
+            run += c[j];
+        }
+    }
+    __syncthreads();
+    plan_body(a, bits, sm, red);
 }
 
 // ---------------------------------------------------------------- hash tables
