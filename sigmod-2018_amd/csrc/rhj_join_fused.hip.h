@@ -1,0 +1,900 @@
+// rhj_join_fused.hip.h — fused LDS join: CSR slot index, probe with stash, chained output offsets, deferred streaming emit
+// (part of the device code of librhj.so; rhj_kernels.hip.h includes all of it)
+#pragma once
+#include "rhj_common.hip.h"
+#include "rhj_partition.hip.h"
+#include "rhj_join_tiled.hip.h"
+
+namespace rhj {
+
+// ------------------------------------------------------------- fused LDS join
+//
+// One persistent workgroup per CU takes units = (bucket, up to FJ_SPAN probe tuples) in canonical
+// order through a ticket, so that a unit's predecessors are always running or done.
+//   build    CSR slot index of the bucket's build side in LDS (fj_build)
+//   phase 1  stream the unit's probe keys; one 8-entry tag window per tuple in LDS; ONE global
+//            gather per candidate (key to verify + row id) — from LDS instead when the build
+//            tuples fit there too (RES, build side <= ~7 K tuples); per probe tuple stash the
+//            match count (u8) and the first match's build row id (u64), further matches go to
+//            the overflow stash (fj_count_batch)
+//   chain    publish the unit's match total right away (8-byte {flag,value} word per unit,
+//            agent-scope relaxed atomics)
+//   emit     deferred behind the NEXT unit's build and phase 1: decoupled look-back over the
+//            predecessors (never waits by then), then stream probe row ids + stash + overflow
+//            stash and write the pairs at their final canonical positions (fj_emit_stream).
+//            Units the overflow stash cannot describe emit immediately by walking the index again.
+// Random global accesses per probe tuple: one 128-byte line (the gather); everything
+// else is streaming or LDS.
+constexpr int FJ_BLOCK = 1024;
+constexpr int FJ_WAVES = FJ_BLOCK / WAVE;
+constexpr int FJ_V = 4;
+constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
+constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
+constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
+constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
+constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
+constexpr uint32_t FJ_GROUPS = FJ_SPAN / 256;   // a group = the 256 tuples one wave counts in one batch
+
+struct FusedArgs {
+    JoinArgs  j;
+    uint8_t  *stash_cnt;      // [nR + nS] matches per probe tuple, saturating at 255
+    uint64_t *stash_row;      // [nR + nS] build row id of the first match
+    uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
+    uint32_t *ticket;
+    uint64_t  nR;
+    uint32_t  allow_resident;
+    uint32_t  pad;
+    uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
+    uint64_t *ovf;            // [grid][2][FJ_OVF_CAP] build row ids of second and later matches (per workgroup, double-buffered)
+    uint32_t *ovf_base;       // [grid][2][FJ_SPAN / 256][16] first overflow slot of (256-tuple group, match ordinal)
+};
+
+
+// LDS index of the fused kernel: the build positions of a bucket grouped by hash slot (CSR).
+//   ent[p]   tag16 << 16 | build position, the entries of one slot contiguous and in DESCENDING value
+//            order.  Equal keys have equal tags, so the positions of one key come out descending —
+//            the order in which the reference's bucket/chain index hands out the matches of a key
+//            (CreateIndex walks last->first and appends at the tail, rhjoin.c:219-250).  Tags are
+//            1..0xfffe: 0 is the empty cell during the build, 0xffff the 8 pad entries behind the array.
+//   H[s + 1] 16-bit start of slot s in ent[], H[s + 2] its end (two per 32-bit word)
+// Built by a counting sort in LDS: count per slot, exclusive scan, then every tuple enters its slot's
+// range by ordered insertion (atomicMax on the cell, carry the smaller value to the next cell: the
+// range ends up sorted for every interleaving, like the chains this replaces).  A probe reads the
+// slot's start and end and a window of 8 entries, compares the 8 tags at once and keeps a bit mask of
+// the hits: no pointer chasing and no loop whose trip count is the longest chain of the wave (the
+// linked chains spent 2/3 of the probe's vector instructions there).  Slots longer than 8 continue
+// window by window.
+struct FjIndex {
+    uint32_t *ent;       // [bc + 8]
+    uint32_t *dirw;      // [(hs + 3) / 2]
+    uint32_t  hs;
+    __device__ __forceinline__ uint32_t slot(uint64_t h) const { return __umulhi((uint32_t)(h >> 32), hs); }
+    __device__ __forceinline__ uint32_t H(uint32_t j) const { return reinterpret_cast<const uint16_t *>(dirw)[j]; }
+};
+__device__ __forceinline__ uint32_t fj_tag(uint64_t h) { return min((uint32_t)(h >> 16) & 0xffffu, 0xfffdu) + 1u; }
+
+// Partitioned relations as the fused kernel sees them: rhj_tuple (16 B), or — N32: the partition found every row id
+// below 2^32 and wrote Tuple12 — 12 bytes per tuple.  Whole tuple as {key lo, key hi, row id lo, row id hi}.
+template <bool N32> __device__ __forceinline__ uint4 pt_load(const rhj_tuple *base, uint64_t i)
+{
+    if (N32) { const Tuple12 x = reinterpret_cast<const Tuple12 *>(base)[i]; return make_uint4(x.klo, x.khi, x.rid, 0u); }
+    return reinterpret_cast<const uint4 *>(base)[i];
+}
+template <bool N32> __device__ __forceinline__ uint2 pt_load_key(const rhj_tuple *base, uint64_t i)
+{
+    if (N32) { const Tuple12 *x = reinterpret_cast<const Tuple12 *>(base) + i; return make_uint2(x->klo, x->khi); }
+    return reinterpret_cast<const uint2 *>(base)[2 * i];
+}
+
+// hit mask of the first min(n, 8) entries of the window at `start`
+__device__ __forceinline__ uint32_t fj_window(const FjIndex &X, uint32_t start, uint32_t n, uint32_t tgs)
+{
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = X.ent[start + j];
+    const uint32_t tg = tgs >> 16;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m |= ((e[j] >> 16) == tg) ? (1u << j) : 0u;
+    return m & ((1u << min(n, 8u)) - 1u);
+}
+
+// Per probe tuple: sn = window start | remaining slot length << 16, tm = tag << 16 | hit mask of the
+// current window.
+__device__ __forceinline__ void fj_lookup(const FjIndex &X, uint64_t key, bool ok, uint32_t &sn, uint32_t &tm)
+{
+    const uint64_t h = mix64(key);
+    const uint32_t s = X.slot(h);
+    const uint32_t d0 = X.H(s + 1u), n = ok ? X.H(s + 2u) - d0 : 0u;
+    const uint32_t tgs = fj_tag(h) << 16;
+    sn = d0 | (n << 16);
+    tm = tgs | fj_window(X, d0, n, tgs);
+}
+
+// One round of the probe: every tuple that still has a candidate hands out its next one (pos[k], a
+// build position) — first from the window's hit mask, and when that is used up and the slot is longer
+// than the window, from the next window.  Returns whether any lane of the wave got a candidate.
+__device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V], uint32_t (&tm)[FJ_V], uint32_t (&pos)[FJ_V],
+                                         bool &last)
+{
+    bool more = false;
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u);
+    while (__ballot(more) != 0) {                     // rare: a slot with more than 8 entries
+        more = false;
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            if ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u) {
+                sn[k] += 8u - (8u << 16);             // start += 8, length -= 8
+                tm[k] |= fj_window(X, sn[k] & 0xffffu, sn[k] >> 16, tm[k] & 0xffff0000u);
+                more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u);
+            }
+        }
+    }
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        pos[k] = 0xffffffffu;
+        const uint32_t m = tm[k] & 0xffu;
+        if (m != 0) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            pos[k] = X.ent[(sn[k] & 0xffffu) + j] & 0xffffu;
+            tm[k] &= tm[k] - 1u;                      // the mask sits in the low bits
+            found = true;
+        }
+    }
+    bool rest = false;                                // spares the caller a round that finds nothing
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) rest = rest || (tm[k] & 0xffu) != 0 || (sn[k] >> 16) > 8u;
+    last = __ballot(rest) == 0;
+    return __ballot(found) != 0;
+}
+
+// Build the index of one bucket's build side (whole workgroup).  RES: the tuples are copied to LDS
+// on the way and the second pass reads them there.  `tmp` is global scratch of at least 4 * bc bytes
+// for the cooperative sort of long slots.
+constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
+constexpr int FJ_SMALL = 4;                           // batches of 4096 build tuples whose (slot, tag) words are kept for the fill pass
+template <bool RES, bool N32>
+__device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *part, uint64_t boff, uint32_t bc, uint4 *ltup,
+                                         uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t ndw = (X.hs + 3u) / 2u;
+    for (uint32_t i = tid; i < ndw; i += FJ_BLOCK) X.dirw[i] = 0;
+    for (uint32_t i = tid; i < bc; i += FJ_BLOCK) X.ent[i] = 0;
+    if (tid < 8) X.ent[bc + tid] = 0xffff0000u;
+    __syncthreads();
+    // ---- count: H[s + 1] += 1.  Build sides of up to 4 batches (16 K tuples) are hashed only once: the
+    // (slot, tag) word of tuple i is parked in ent[i], picked up into registers before the fill pass
+    // clears the array, and the fill pass needs neither the key nor a second hash.
+    const bool small = bc <= FJ_SMALL * FJ_BATCH;
+    {
+        uint4 t[FJ_V], tn[FJ_V];                       // current and prefetched batch of build tuples
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = k * FJ_BLOCK + tid;
+            t[k] = make_uint4(0, 0, 0, 0);
+            if (i < bc) { if (RES) t[k] = pt_load<N32>(part, boff + i); else { const uint2 kv = pt_load_key<N32>(part, boff + i); t[k].x = kv.x; t[k].y = kv.y; } }
+        }
+        for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {               // next batch's loads fly while this batch is counted
+                const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + tid;
+                tn[k] = make_uint4(0, 0, 0, 0);
+                if (i < bc) { if (RES) tn[k] = pt_load<N32>(part, boff + i); else { const uint2 kv = pt_load_key<N32>(part, boff + i); tn[k].x = kv.x; tn[k].y = kv.y; } }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = i0 + k * FJ_BLOCK + tid;
+                if (i < bc) {
+                    if (RES) ltup[i] = t[k];
+                    const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
+                    const uint32_t sl = X.slot(h);
+                    if (small) X.ent[i] = (sl << 16) | fj_tag(h);       // parked in the still unused entry array
+                    const uint32_t j = sl + 1u;
+                    atomicAdd(&X.dirw[j >> 1], (j & 1u) ? 0x10000u : 1u);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) t[k] = tn[k];
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan over the halfwords: H[s + 1] = start of slot s, H[hs + 1] = bc
+    {
+        const uint32_t chunk = (ndw + FJ_BLOCK - 1u) / FJ_BLOCK;
+        const uint32_t lo = min(tid * chunk, ndw), hi = min(lo + chunk, ndw);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = X.dirw[i]; sum += (v & 0xffffu) + (v >> 16); }
+        uint32_t tot;
+        uint32_t run = wave_excl_scan_u32(sum, &tot);
+        if (lane == 0) wsum[w] = tot;
+        __syncthreads();
+        for (uint32_t i = 0; i < w; ++i) run += wsum[i];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t v = X.dirw[i];
+            const uint32_t a0 = run; run += v & 0xffffu;
+            const uint32_t a1 = run; run += v >> 16;
+            X.dirw[i] = a0 | (a1 << 16);
+        }
+    }
+    __syncthreads();
+    // ---- fill.  Ordered insertion into the slot's range: atomicMax on the cell, go on with the
+    // smaller of the two values; exactly n values enter n cells, so a carry always finds an empty cell
+    // inside the range.  Long slots (many duplicates of one key, where that would be quadratic) take
+    // places in arrival order — the range's last cell counts the arrivals until the last arrival
+    // overwrites it — and are ranked afterwards.
+    bool has_long = false;
+    auto insert = [&](uint32_t sl, uint32_t v) {
+        const uint32_t a = X.H(sl + 1u), n = X.H(sl + 2u) - a;
+        if (n <= FJ_LONG) {
+            for (uint32_t p = a;; ++p) {
+                const uint32_t old = atomicMax(&X.ent[p], v);
+                if (old == 0) break;
+                v = min(old, v);
+            }
+        } else {
+            has_long = true;
+            const uint32_t arrival = atomicAdd(&X.ent[a + n - 1u], 1u);
+            X.ent[a + arrival] = v;                  // arrival n - 1: everybody has counted, the counter cell is free
+        }
+    };
+    if (small) {
+        uint32_t hw[FJ_SMALL][FJ_V];
+#pragma unroll
+        for (int b = 0; b < FJ_SMALL; ++b)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = (uint32_t)b * FJ_BATCH + k * FJ_BLOCK + tid;
+                hw[b][k] = i < bc ? X.ent[i] : 0;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < FJ_SMALL; ++b)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = (uint32_t)b * FJ_BATCH + k * FJ_BLOCK + tid;
+                if (i < bc) X.ent[i] = 0;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < FJ_SMALL; ++b)
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = (uint32_t)b * FJ_BATCH + k * FJ_BLOCK + tid;
+                if (i < bc) insert(hw[b][k] >> 16, (hw[b][k] << 16) | i);
+            }
+    } else {
+        uint4 t[FJ_V], tn[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = k * FJ_BLOCK + tid;
+            t[k] = make_uint4(0, 0, 0, 0);
+            if (i < bc) { if (RES) t[k] = ltup[i]; else { const uint2 kv = pt_load_key<N32>(part, boff + i); t[k].x = kv.x; t[k].y = kv.y; } }
+        }
+        for (uint32_t i0 = 0; i0 < bc; i0 += FJ_BATCH) {
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = i0 + FJ_BATCH + k * FJ_BLOCK + tid;
+                tn[k] = make_uint4(0, 0, 0, 0);
+                if (i < bc) { if (RES) tn[k] = ltup[i]; else { const uint2 kv = pt_load_key<N32>(part, boff + i); tn[k].x = kv.x; tn[k].y = kv.y; } }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = i0 + k * FJ_BLOCK + tid;
+                if (i < bc) {
+                    const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
+                    insert(X.slot(h), (fj_tag(h) << 16) | i);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) t[k] = tn[k];
+        }
+    }
+    if (__syncthreads_or(has_long)) {
+        // long slots: one at a time, ranked by the whole workgroup (descending value)
+        for (uint32_t next = 0;;) {
+            if (tid == 0) *sh_pick = 0xffffffffu;
+            __syncthreads();
+            for (uint32_t sl = tid; sl < X.hs; sl += FJ_BLOCK)
+                if (sl >= next && X.H(sl + 2u) - X.H(sl + 1u) > FJ_LONG) { atomicMin(sh_pick, sl); break; }
+            __syncthreads();
+            const uint32_t pick = *sh_pick;
+            if (pick == 0xffffffffu) break;
+            const uint32_t a = X.H(pick + 1u), n = X.H(pick + 2u) - a;
+            for (uint32_t i = tid; i < n; i += FJ_BLOCK) {
+                const uint32_t v = X.ent[a + i];
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < n; ++j) r += X.ent[a + j] > v;
+                tmp[r] = v;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += FJ_BLOCK) X.ent[a + i] = tmp[i];
+            next = pick + 1u;
+            __syncthreads();
+        }
+    }
+}
+
+// Count the matches of one batch (FJ_V probe tuples per lane): lockstep rounds of
+// {walk every live chain to its next tag hit (LDS), fetch those candidates' build tuples
+// together, verify the 64-bit keys}.  RES: the build tuples are resident in LDS (no global
+// access at all); otherwise each candidate is one 16-byte gather from the bucket's build side.
+// Gathers of build tuples go through a buffer descriptor of the bucket's build side and carry
+// sc1 (L1 bypass): a gathered line is used once per candidate, so allocating it in the 32 KiB
+// vector L1 only evicts the streamed probe data.  A/B on MI355X (tools/ab.py, fused kernel on
+// 100Mx100M@12): plain 4.64 ms, nt 4.06 ms, sc1 3.8 ms.
+template <bool N32>
+struct FjGather {
+    __amdgpu_buffer_rsrc_t rsrc;
+    static constexpr uint32_t STRIDE = N32 ? 12u : 16u;
+    __device__ __forceinline__ void init(const rhj_tuple *part, uint64_t boff, uint32_t bc)
+    {
+        const uint64_t addr = (uint64_t)part + boff * STRIDE;     // wave-uniform by construction: make it provable
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        const uint32_t bytes = __builtin_amdgcn_readfirstlane(bc * STRIDE);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+    }
+    __device__ __forceinline__ uint4 load(uint32_t pos) const
+    {
+        if (N32) {
+            typedef uint32_t v3 __attribute__((ext_vector_type(3)));
+            const v3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(pos * 12u), 0, 16 /* sc1 */);
+            return make_uint4(v.x, v.y, v.z, 0u);
+        }
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, 16 /* sc1 */);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+};
+
+// Overflow stash of the gather path.  Phase 1 has every match's build row id in registers at the
+// moment it verifies it, so besides the first one (stash_row) it keeps the others too: a wave that
+// finds second-or-later matches in round r (r = 1, 2, ...; a tuple whose tag hits are all matches
+// finds its (r+1)-th match exactly there) takes a contiguous run of slots with one LDS atomic, records
+// the run's start for (its 256-tuple group, r) and stores the row ids in (k, lane) order.  The emit
+// pass recomputes the same ranks from the stashed counts, so it needs neither the index nor a gather
+// and can run any time later.  Tuples that break the rule (a tag hit with a foreign key next to two or
+// more matches, more than 16 matches, capacity) make the unit fall back to the index walk.
+struct FjOvf {
+    uint64_t *buf;        // this unit's overflow entries
+    uint32_t *table;      // this unit's [group][16] run starts
+    uint32_t *counter;    // LDS bump counter
+    uint32_t  gid;        // group of this wave in this batch
+};
+
+template <bool RES, bool OVF, bool N32>
+__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather<N32> &G, const uint4 *ltup,
+                                               const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
+                                               uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
+                                               const FjOvf &O)
+{
+    uint32_t sn[FJ_V], tm[FJ_V];
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        fj_lookup(X, ((uint64_t)q[k].y << 32) | q[k].x, okk[k], sn[k], tm[k]);
+        c[k] = 0; flo[k] = 0; fhi[k] = 0; fp[k] = false;
+    }
+    bool last = false;
+    for (uint32_t round = 0; !last; ++round) {
+        uint32_t pos[FJ_V];
+        if (!fj_round(X, sn, tm, pos, last)) break;
+        uint4 g[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            g[k] = make_uint4(0, 0, 0, 0);
+            if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : G.load(pos[k]);
+        }
+        bool ex[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
+            if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
+            ex[k] = OVF && eq && c[k] != 0;
+            c[k] += eq;
+            fp[k] = fp[k] || (pos[k] != 0xffffffffu && !eq);      // a tag hit with a different key
+        }
+        if (OVF && round != 0) {
+            uint64_t mk[FJ_V];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) { mk[k] = __ballot(ex[k]); tot += (uint32_t)__popcll(mk[k]); }
+            if (tot != 0) {
+                const uint32_t lane = threadIdx.x & 63;
+                const uint64_t lt = lanemask_lt();
+                uint32_t base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(O.counter, tot);
+                    if (round <= FJ_OVF_J) O.table[O.gid * 16u + round] = base;
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                uint32_t pre = base;
+#pragma unroll
+                for (int k = 0; k < FJ_V; ++k) {
+                    const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
+                    if (ex[k] && slot < FJ_OVF_CAP) reinterpret_cast<uint2 *>(O.buf)[slot] = make_uint2(g[k].z, g[k].w);
+                    pre += (uint32_t)__popcll(mk[k]);
+                }
+            }
+        }
+    }
+}
+
+// Exclusive prefix of unit u > 0 in the chained scan (called by ONE wave): sums the predecessors'
+// words 64 at a time until it meets an inclusive prefix; waits only for aggregates, which every unit
+// publishes right after its phase 1.
+__device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t u, uint32_t lane)
+{
+    uint64_t excl = 0;
+    int64_t j = (int64_t)u - 1;
+    for (;;) {
+        const int64_t idx = j - lane;
+        unsigned long long v = 2ull << 62;    // virtual "prefix 0" in front of unit 0
+        if (idx >= 0) {
+            do {
+                v = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2);
+            } while ((v >> 62) == 0);
+        }
+        const uint64_t full = __ballot((v >> 62) == 2);
+        const int stop = full ? __ffsll((unsigned long long)full) - 1 : 64;   // nearest inclusive prefix
+        uint64_t part = lane <= (uint32_t)stop ? (v & ((1ull << 62) - 1)) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        excl += part;
+        if (full) break;
+        j -= 64;
+    }
+    return excl;
+}
+
+// The first-match stash is 8 bytes per probe tuple: the build row id — or, when the partition found every row
+// id below 2^32 (N32: summary->wide_row_ids == 0; pass 1 checks every tuple and the host runs again wide
+// otherwise), the low words of the build AND the probe row id, so that the deferred emit pass does not read
+// the probe tuples again.
+template <bool N32> __device__ __forceinline__ void fj_stash_put(uint2 *srow, uint32_t i, uint32_t lo, uint32_t hi, uint32_t probe_lo)
+{
+    srow[i] = N32 ? make_uint2(lo, probe_lo) : make_uint2(lo, hi);
+}
+
+// Deferred emit pass of a gather-path unit: pure streaming of the probe row ids, the stash and (DUP)
+// the overflow stash, 8 tuples per lane; the index is not needed.  DUP = false: every probe tuple has
+// zero or one match (the foreign-key case), offsets come from ballots.
+template <bool DUP, bool N32>
+__device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum,
+                                               const uint64_t *ovf, uint32_t *table, uint32_t *grab)
+{
+    constexpr int V = FJ_V;                           // a wave's step is one 256-tuple group of phase 1
+    const JoinArgs &a = f.j;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const Unit un = a.units[u];
+    const uint32_t b = un.bucket;
+    const bool flip = a.histR[b] < a.histS[b];
+    const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
+    const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
+    const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
+    const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    const uint64_t cap = a.out_capacity;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t ngroups = (un.count + 255u) >> 8;
+
+    // group totals (phase 1 left them in column 0 of the table) -> exclusive starts, once per unit;
+    // after that the waves run without any barrier
+    {
+        const uint32_t t = threadIdx.x;
+        uint32_t v = 0;
+        if (t < ngroups) v = __hip_atomic_load(&table[t * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t tot;
+        uint32_t ex = wave_excl_scan_u32(v, &tot);
+        __syncthreads();                              // wsum reuse
+        if (t == 0) *grab = 0;
+        if (lane == 0) wsum[w] = tot;
+        __syncthreads();
+        for (uint32_t i = 0; i < w && i < FJ_GROUPS / WAVE; ++i) ex += wsum[i];
+        if (t < ngroups) __hip_atomic_store(&table[t * 16u], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+    }
+
+    for (;;) {                                        // groups are handed out as in phase 1
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(grab, 1u);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
+        uint32_t c[V];
+        uint2 first[V], prow[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const uint32_t i = g * 256u + k * WAVE + lane;
+            const bool ok = i < un.count;
+            c[k] = ok ? (scnt[i] & 0x7fu) : 0;
+            first[k] = ok ? srow[i] : make_uint2(0, 0);
+            if (N32) { prow[k] = make_uint2(first[k].y, 0u); first[k].y = 0u; }
+            else     prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
+        }
+        // the group's table row: lane 0 its start in the unit's output, lane j the run start of ordinal j
+        uint32_t tbl_v = 0;
+        if (lane < 16) tbl_v = __hip_atomic_load(&table[g * 16u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t off[V], wrun = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (DUP) {
+                uint32_t tot;
+                off[k] = wrun + wave_excl_scan_u32(c[k], &tot);
+                wrun += tot;
+            } else {
+                const uint64_t m = __ballot(c[k] != 0);
+                off[k] = wrun + (uint32_t)__popcll(m & lt);
+                wrun += (uint32_t)__popcll(m);
+            }
+        }
+        const uint64_t wbase = base + (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, 0);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const uint64_t at = wbase + off[k];
+            if (c[k] != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
+        }
+        if (DUP) {
+            // second and later matches: ordinal j of the group's tuples sits in one run of the overflow
+            // stash, in (k, lane) order (fj_count_batch).  Four ordinals per step, loads before stores.
+            for (uint32_t j0 = 1;; j0 += 4) {
+                uint2 r[4][V];
+                bool any = false;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t j = j0 + jj;
+                    uint64_t mk[V];
+                    uint32_t tot = 0;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) { mk[k] = __ballot(c[k] > j); tot += (uint32_t)__popcll(mk[k]); }
+                    any = any || tot != 0;
+                    uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, (int)(j & 15u));
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
+                        r[jj][k] = make_uint2(0, 0);
+                        if (c[k] > j) r[jj][k] = reinterpret_cast<const uint2 *>(ovf)[slot];
+                        pre += (uint32_t)__popcll(mk[k]);
+                    }
+                }
+                if (!any) break;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const uint64_t at = wbase + off[k] + j0 + jj;
+                        if (c[k] > j0 + jj && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, r[jj][k].x, r[jj][k].y);
+                    }
+                }
+                if (j0 + 4 > FJ_OVF_J) break;
+            }
+        }
+    }
+}
+
+// MAYRES = false compiles the gather path only (the host picks it when the average bucket
+// cannot fit LDS anyway); MAYRES = true decides per unit.
+// A workgroup takes units through the ticket until none is left.  The emit pass of a unit that does
+// not need its index any more (no probe tuple with two or more matches: the foreign-key case) is
+// DEFERRED behind the next unit's build + phase 1: by then its output base has long been published,
+// so such units never wait on the chain (the wait was 18 % of a unit in the in-kernel stamps).
+// Diagnostics of the fused kernel (in-kernel phase stamps, RHJ_STAMPS; parts switched off, RHJ_ABLATE)
+// are compiled in only with -DRHJ_INSTRUMENT (tools/): the production kernel carries no trace of them.
+#ifdef RHJ_INSTRUMENT
+#define FJ_DBG (f.dbg)
+#define FJ_ABLATE (a.ablate)
+#else
+#define FJ_DBG ((uint64_t *)nullptr)
+#define FJ_ABLATE 0u
+#endif
+template <bool MAYRES, bool N32>
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
+    __shared__ uint32_t sh_u;
+    __shared__ uint32_t sh_ovf;
+    __shared__ uint32_t sh_grab;
+    __shared__ uint32_t sh_pick;
+    __shared__ uint64_t sh_base;
+    __shared__ uint32_t wsum[FJ_WAVES];
+    const JoinArgs &a = f.j;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long *st = (unsigned long long *)f.status;
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    const uint64_t cap = a.out_capacity;
+    const bool emitting = out != nullptr && FJ_ABLATE != 3;
+    if ((a.summary->wide_row_ids == 0) != N32) return;                 // the other instantiation's launch does the join
+    uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
+    uint64_t pend_total = 0;
+    bool pend_dup = false;
+    const uint64_t *pend_ovf = nullptr;
+    uint32_t *pend_table = nullptr;
+
+    for (uint32_t iter = 0;; ++iter) {
+    __syncthreads();
+    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; sh_grab = 0; }
+    __syncthreads();
+    const uint32_t u = sh_u;
+    if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
+    const Unit un = a.units[u];
+    const uint32_t b = un.bucket;
+    const uint64_t cR = a.histR[b], cS = a.histS[b];
+    const bool flip = cR < cS;                                         // S is streamed (r_s == 1)
+    const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;   // position in the probe relation
+    const rhj_tuple *prp = flip ? a.partS : a.partR;                   // probe tuple i of the unit: pt_load<N32>(prp, ppos + i)
+    const rhj_tuple *bdp = flip ? a.partR : a.partS;                   // build tuple i of the bucket: pt_load<N32>(bdp, bpos + i)
+    const uint64_t bpos = flip ? a.psumR[b] : a.psumS[b];
+    const uint32_t bc = (uint32_t)(flip ? cR : cS);
+    // LDS: [resident build tuples 16 B x bc] [entries 4 B x (bc + 8)] [slot starts 2 B x (hs + 1)]
+    const uint32_t bcp = (bc + 3u) & ~3u;
+    // slots: one per build tuple when that fits behind the entries, fewer (longer slots) for the
+    // largest build sides, never below a quarter (host-side cap: 4.5 B per build tuple)
+    uint32_t hs0 = bc < 64u ? 64u : bc;
+    {
+        const uint32_t room = (lds_bytes - 64u - 4u * bcp) / 2u - 2u; // 16-bit slot starts that still fit
+        if (hs0 > room) hs0 = room & ~1u;
+    }
+    // build tuples go to LDS too when they fit beside the index (wave-uniform per unit)
+    const bool RES = MAYRES && f.allow_resident && (size_t)bcp * 20 + (size_t)(hs0 + 3) / 2 * 4 + 64 <= lds_bytes;
+    uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
+    FjIndex X;
+    X.ent = tbl + (RES ? 4u * bcp : 0u);
+    X.hs = hs0;
+    X.dirw = X.ent + bcp + 8u;
+    uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
+    uint2 *srow = reinterpret_cast<uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
+    FjGather<N32> G;
+    G.init(bdp, bpos, bc);
+    FjOvf O;                                          // double-buffered: the previous unit's emit may still be pending
+    O.buf = f.ovf + ((size_t)blockIdx.x * 2 + (iter & 1u)) * FJ_OVF_CAP;
+    O.table = f.ovf_base + ((size_t)blockIdx.x * 2 + (iter & 1u)) * (FJ_GROUPS * 16u);
+    O.counter = &sh_ovf;
+    O.gid = 0;
+
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    // ---- build
+    if (RES) fj_build<true, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
+    else     fj_build<false, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
+    if (FJ_ABLATE == 1) continue;                      // timing experiment: build only
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
+    uint32_t mine = 0;
+    bool needs_index = false;                         // the emit pass must walk the index again
+    // The waves take 256-tuple groups from a workgroup counter: with a fixed share per wave the barrier
+    // behind this loop waited 20 us of a 156 us unit for the slowest wave's gathers.
+    const uint32_t ngroups1 = (un.count + 255u) >> 8;
+    for (;;) {
+        uint32_t grp = 0;
+        if (lane == 0) grp = atomicAdd(&sh_grab, 1u);
+        grp = __builtin_amdgcn_readfirstlane(grp);
+        if (grp >= ngroups1) break;
+        const uint32_t t0 = grp << 8;
+        uint4 q[FJ_V];
+        bool okk[FJ_V];
+        uint32_t c[FJ_V], flo[FJ_V], fhi[FJ_V];
+        bool fp[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = t0 + k * WAVE + lane;
+            okk[k] = i < un.count;
+            q[k] = okk[k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
+        }
+        O.gid = grp;
+        if (RES) fj_count_batch<true, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const uint32_t i = t0 + k * WAVE + lane;
+            if (i < un.count) {
+                // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
+                // this tuple was a different key, so phase 2 must verify its candidates again
+                scnt[i] = (uint8_t)(min(c[k], 127u) | (fp[k] ? 0x80u : 0u));
+                fj_stash_put<N32>(srow, i, flo[k], fhi[k], q[k].z);
+            }
+            mine += c[k];
+            needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
+        }
+        {                                             // group total for the barrier-free emit pass
+            uint32_t gt;
+            wave_excl_scan_u32(c[0] + c[1] + c[2] + c[3], &gt);
+            if (lane == 0) O.table[O.gid * 16u] = gt;
+        }
+    }
+
+    // ---- unit total -> chained scan
+    if (FJ_DBG && lane == 0) { if (w == 0) FJ_DBG[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
+    {
+        uint32_t tot;
+        wave_excl_scan_u32(mine, &tot);
+        if (lane == 0) wsum[w] = tot;
+    }
+    bool unit_needs_index = __syncthreads_or(needs_index) != 0;   // also publishes wsum
+    const uint32_t ovf_total = sh_ovf;
+    unit_needs_index = unit_needs_index || ovf_total > FJ_OVF_CAP;
+    uint64_t total = 0;
+#pragma unroll
+    for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
+    if (threadIdx.x == 0) {
+        // aggregate first: successors only ever wait for this word
+        __hip_atomic_store(&st[u], ((u == 0 ? 2ull : 1ull) << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.unit_count[u] = total;
+    }
+
+    // ---- the deferred emit pass of the previous unit, whose base is certainly known by now
+    if (pend != 0xffffffffu) {
+        if (w == 0) {
+            const uint64_t excl = pend == 0 ? 0 : fj_lookback(st, pend, lane);
+            if (lane == 0) {
+                if (pend != 0) __hip_atomic_store(&st[pend], (2ull << 62) | (excl + pend_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_base = excl;
+            }
+        }
+        __syncthreads();
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        pend = 0xffffffffu;
+        __syncthreads();
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (emitting && !unit_needs_index) {              // this unit's emit pass needs no index: defer it
+        pend = u;
+        pend_total = total;
+        pend_dup = ovf_total != 0;
+        pend_ovf = O.buf;
+        pend_table = O.table;
+        if (FJ_DBG && threadIdx.x == 0) { FJ_DBG[(size_t)u * 8 + 3] = FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
+        continue;
+    }
+
+    if (w == 0) {
+        const uint64_t excl = u == 0 ? 0 : fj_lookback(st, u, lane);
+        if (lane == 0) {
+            if (u != 0) __hip_atomic_store(&st[u], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_base = excl;
+        }
+    }
+    __syncthreads();
+
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    // ---- phase 2: emit (general form: duplicates and tag collisions walk the index again)
+    uint64_t run = sh_base;
+    if (!emitting) continue;
+    // FJ_H batches per iteration; a wave's slice of the iteration is contiguous: order (wave, half,
+    // round, lane).  FJ_H = 2 (more loads in flight, half the barriers) measured +11 % on the kernel:
+    // it spills at the 128-VGPR limit of a 1024-thread workgroup.
+    constexpr int FJ_H = 1;
+    for (uint32_t t0 = 0; t0 < un.count; t0 += FJ_H * FJ_BATCH) {
+        uint32_t c[FJ_H][FJ_V], flo[FJ_H][FJ_V], fhi[FJ_H][FJ_V];
+        uint4 q[FJ_H][FJ_V];
+        bool okk[FJ_H][FJ_V], fpt[FJ_H][FJ_V];
+#pragma unroll
+        for (int h = 0; h < FJ_H; ++h) {
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = t0 + w * (WAVE * FJ_V * FJ_H) + h * (WAVE * FJ_V) + k * WAVE + lane;
+                okk[h][k] = i < un.count;
+                fpt[h][k] = false;
+                q[h][k] = okk[h][k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
+                const uint32_t sb = okk[h][k] ? scnt[i] : 0;
+                c[h][k] = sb & 0x7fu;
+                fpt[h][k] = (sb & 0x80u) != 0;
+                const uint2 fr = okk[h][k] ? srow[i] : make_uint2(0, 0);
+                flo[h][k] = fr.x; fhi[h][k] = N32 ? 0u : fr.y;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < FJ_H; ++h) {
+            {
+                // saturated counts: recount from the index (also yields the exact number to emit)
+#pragma unroll
+                for (int k = 0; k < FJ_V; ++k) {
+                    if (c[h][k] == 127u) {
+                        const uint64_t hh = mix64(((uint64_t)q[h][k].y << 32) | q[h][k].x);
+                        const uint32_t t = fj_tag(hh), sl = X.slot(hh);
+                        uint32_t n = 0;
+                        for (uint32_t at = X.H(sl + 1u), end = X.H(sl + 2u); at < end; ++at) {
+                            const uint32_t nd = X.ent[at];
+                            if ((nd >> 16) == t) { const uint4 v = RES ? ltup[nd & 0xffffu] : G.load(nd & 0xffffu); n += (v.x == q[h][k].x && v.y == q[h][k].y); }
+                        }
+                        c[h][k] = n;
+                    }
+                }
+            }
+        }
+        uint32_t off[FJ_H][FJ_V], wrun = 0;
+#pragma unroll
+        for (int h = 0; h < FJ_H; ++h) {
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                uint32_t tot;
+                off[h][k] = wrun + wave_excl_scan_u32(c[h][k], &tot);
+                wrun += tot;
+            }
+        }
+        __syncthreads();                              // wsum reuse
+        if (lane == 0) wsum[w] = wrun;
+        __syncthreads();
+        uint64_t wbase = run;
+        uint32_t batch_total = 0;
+#pragma unroll
+        for (int i = 0; i < FJ_WAVES; ++i) {
+            const uint32_t v = wsum[i];
+            if ((uint32_t)i < w) wbase += v;
+            batch_total += v;
+        }
+        run += batch_total;
+        // The first match comes from the stash (phase 1 kept its row id).  Further matches of a tuple
+        // are fetched in lockstep rounds over its chain; when no tag hit of the tuple was a foreign key
+        // (the rule: stash bit 7 clear) its first candidate IS that first match and is skipped unfetched.
+#pragma unroll
+        for (int h = 0; h < FJ_H; ++h) {
+            uint64_t at[FJ_V];
+            uint32_t sn[FJ_V], tm[FJ_V];
+            bool skip[FJ_V];
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                at[k] = wbase + off[h][k];
+                const bool direct = c[h][k] >= 1 && !fpt[h][k];             // stash holds its first emitted pair
+                if (direct) { if (at[k] < cap) out[at[k]] = make_pair(flip, q[h][k].z, q[h][k].w, flo[h][k], fhi[h][k]); ++at[k]; }
+                const bool walk = direct ? c[h][k] >= 2 : c[h][k] >= 1;
+                fj_lookup(X, ((uint64_t)q[h][k].y << 32) | q[h][k].x, walk, sn[k], tm[k]);
+                skip[k] = direct;
+            }
+            bool last = false;
+            for (bool first_round = true; !last; first_round = false) {
+                uint32_t pos[FJ_V];
+                if (!fj_round(X, sn, tm, pos, last)) break;
+                if (first_round) {
+#pragma unroll
+                    for (int k = 0; k < FJ_V; ++k)
+                        if (skip[k]) pos[k] = 0xffffffffu;            // already emitted from the stash
+                }
+                uint4 g[FJ_V];
+#pragma unroll
+                for (int k = 0; k < FJ_V; ++k) {
+                    g[k] = make_uint4(0, 0, 0, 0);
+                    if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : G.load(pos[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < FJ_V; ++k) {
+                    if (pos[k] != 0xffffffffu && g[k].x == q[h][k].x && g[k].y == q[h][k].y) {
+                        if (at[k] < cap) out[at[k]] = make_pair(flip, q[h][k].z, q[h][k].w, g[k].z, g[k].w);
+                        ++at[k];
+                    }
+                }
+            }
+        }
+    }
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    }   // ticket loop
+
+    if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup
+        __syncthreads();
+        if (w == 0) {
+            const uint64_t excl = pend == 0 ? 0 : fj_lookback(st, pend, lane);
+            if (lane == 0) {
+                if (pend != 0) __hip_atomic_store(&st[pend], (2ull << 62) | (excl + pend_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_base = excl;
+            }
+        }
+        __syncthreads();
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+    }
+}
+
+// total matches of the fused path = inclusive prefix of the last unit
+__global__ void k_fused_total(const uint64_t *status, const PlanSummary *summary, uint64_t unit_bound, uint64_t *total_out)
+{
+    // when the plan rejected the fused path its unit list is the tiled one and can be longer than the
+    // status array: nothing was published, nothing to read
+    const uint64_t n = summary->units;
+    *total_out = (summary->fused_ok && n && n <= unit_bound) ? (status[n - 1] & ((1ull << 62) - 1)) : 0;
+}
+
+}  // namespace rhj

@@ -1,0 +1,607 @@
+// rhj_partition.hip.h — stable radix partition: one LDS-staged pass (bits <= 8) and two passes in run form (bits 9..15)
+// (part of the device code of librhj.so; rhj_kernels.hip.h includes all of it)
+#pragma once
+#include "rhj_common.hip.h"
+
+namespace rhj {
+
+// ------------------------------------------------------------------ partition
+
+constexpr int PT_BLOCK = 512;                     // threads per partition workgroup
+constexpr int PT_V = 8;                           // tuples per thread
+constexpr int PT_TILE = PT_BLOCK * PT_V;          // 4096 tuples = 64 KiB staged in LDS
+constexpr int PT_WAVES = PT_BLOCK / WAVE;
+constexpr int PT_MAX_BITS = 8;                    // digit bits per pass
+constexpr uint32_t PT_MAX_GROUP = 256;            // pass-1 tiles per pass-2 tile (run form), at most
+
+// The lanes of a wave that hold the same digit as this lane (match-any over `bits` ballots).
+// pb is all ones when the lane's bit is set: peers keeps m where the bit is set and ~m where it is
+// clear, i.e. peers &= ~(m ^ pb), one three-input bit operation per half and bit.
+__device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok, int bits)
+{
+    const uint64_t valid = __ballot(ok);
+    uint32_t plo = (uint32_t)valid, phi = (uint32_t)(valid >> 32);
+#pragma unroll
+    for (int b = 0; b < PT_MAX_BITS; ++b) {
+        if (b < bits) {                               // wave-uniform
+            const uint32_t pb = ok ? 0u - ((d >> b) & 1u) : 0u;
+            const uint64_t m = __ballot(pb != 0);
+            plo &= ~((uint32_t)m ^ pb);
+            phi &= ~((uint32_t)(m >> 32) ^ pb);
+        }
+    }
+    return ((uint64_t)phi << 32) | plo;
+}
+
+// Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
+__global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits)
+{
+    extern __shared__ uint32_t lds_u32[];
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *tile_h = lds_u32;                   // [bins]
+    for (uint32_t tile = blockIdx.x; tile < r.tiles; tile += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) tile_h[b] = 0;
+        __syncthreads();
+        const uint64_t beg = (uint64_t)tile * PT_TILE;
+        const uint64_t end = min(beg + (uint64_t)PT_TILE, r.n);
+#pragma unroll 4
+        for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+            const uint32_t k = (uint32_t)(r.in[i].value >> shift);
+            atomicAdd(&tile_h[k & mask], 1u);
+        }
+        __syncthreads();
+        uint32_t *row = r.cnt + (size_t)tile * bins;
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) row[b] = tile_h[b];
+        __syncthreads();
+    }
+}
+
+// Scan of the per-tile digit counts into per-tile start offsets, in four small kernels:
+//   k_scan_chunks  column sums per (digit, chunk of tiles)         -> chunk_sum[rel][digit][chunk]
+//   k_scan_bins    one wave per digit: exclusive scan over chunks  -> chunk_sum (in place), hist[rel][digit]
+//   k_scan_psum    exclusive scan over digits                      -> psum[rel][digit]
+//   k_scan_apply   counts -> psum[digit] + chunk prefix + tiles before this one (in place)
+__global__ __launch_bounds__(256) void k_scan_chunks(RelArgs r0, RelArgs r1, int bits, uint32_t chunks,
+                                                     uint64_t *chunk_sum /*[2][bins][chunks]*/)
+{
+    const RelArgs &r = blockIdx.z ? r1 : r0;
+    const uint32_t bins = 1u << bits;
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bins) return;
+    const uint32_t per = (r.tiles + chunks - 1) / chunks;
+    const uint32_t t0 = blockIdx.y * per, t1 = min(t0 + per, r.tiles);
+    uint64_t s = 0;
+    for (uint32_t t = t0; t < t1; ++t) s += r.cnt[(size_t)t * bins + b];
+    chunk_sum[((size_t)blockIdx.z * bins + b) * chunks + blockIdx.y] = s;
+}
+
+__global__ __launch_bounds__(WAVE) void k_scan_bins(int bits, uint32_t chunks, uint64_t *chunk_sum, uint64_t *hist)
+{
+    const uint32_t bins = 1u << bits;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    uint64_t *cs = chunk_sum + ((size_t)blockIdx.y * bins + b) * chunks;
+    uint64_t carry = 0;
+    for (uint32_t c0 = 0; c0 < chunks; c0 += WAVE) {
+        const uint32_t c = c0 + lane;
+        const uint64_t v = c < chunks ? cs[c] : 0;
+        uint64_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x += y;
+        }
+        if (c < chunks) cs[c] = carry + x - v;
+        carry += __shfl(x, 63, 64);
+    }
+    if (lane == 0) hist[(size_t)blockIdx.y * bins + b] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_psum(int bits, const uint64_t *hist, uint64_t *psum)
+{
+    __shared__ uint64_t sm[1024 / 64 + 1];
+    const uint32_t bins = 1u << bits;
+    const uint64_t *h = hist + (size_t)blockIdx.x * bins;
+    uint64_t *p = psum + (size_t)blockIdx.x * bins;
+    const uint32_t per = (bins + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t mine = 0;
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) mine += h[b];
+    uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) {
+        p[b] = base;
+        base += h[b];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(RelArgs r0, RelArgs r1, int bits, uint32_t chunks,
+                                                    const uint64_t *chunk_sum, const uint64_t *psum)
+{
+    const RelArgs &r = blockIdx.z ? r1 : r0;
+    const uint32_t bins = 1u << bits;
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bins) return;
+    const uint32_t per = (r.tiles + chunks - 1) / chunks;
+    const uint32_t t0 = blockIdx.y * per, t1 = min(t0 + per, r.tiles);
+    uint64_t run = psum[(size_t)blockIdx.z * bins + b] + chunk_sum[((size_t)blockIdx.z * bins + b) * chunks + blockIdx.y];
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = r.cnt[(size_t)t * bins + b];
+        r.cnt[(size_t)t * bins + b] = (uint32_t)run;
+        run += c;
+    }
+}
+
+// Bucket histogram (u32, from k_hist_tiles' atomics) -> u64 hist + exclusive psum.
+__global__ __launch_bounds__(1024) void k_full_psum(int bits, const uint32_t *full_hist, uint64_t *hist, uint64_t *psum)
+{
+    __shared__ uint64_t sm[1024 / 64 + 1];
+    const uint32_t bins = 1u << bits;
+    const uint32_t *f = full_hist + (size_t)blockIdx.x * bins;
+    uint64_t *h = hist + (size_t)blockIdx.x * bins, *p = psum + (size_t)blockIdx.x * bins;
+    const uint32_t per = (bins + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t mine = 0;
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) mine += f[b];
+    uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
+    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) {
+        h[b] = f[b];
+        p[b] = base;
+        base += f[b];
+    }
+}
+
+// One stable partition pass on digit = (key >> shift) & ((1 << bits) - 1), bits <= 8.
+// Tile order in memory is (wave, round, lane); a tuple's stable rank inside its digit is
+//   digit_start + (same digit in earlier waves) + (same digit in earlier rounds of this
+//   wave) + (same digit in lower lanes of this round)
+// computed with one match-any (bits ballots) per round and per-wave LDS counters — no
+// atomics, so the placement does not depend on any hardware ordering.
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint32_t *delta = dstart + bins;                                           // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(delta + bins);                 // scan scratch
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= r.tiles) return;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint64_t beg = (uint64_t)tile * PT_TILE;
+    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+
+    for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+
+    uint4 t[PT_V];
+    bool ok[PT_V];
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
+        ok[k] = i < count;
+        if (ok[k]) t[k] = in[i];
+    }
+    __syncthreads();
+
+    uint32_t lrank[PT_V], dig[PT_V];
+    uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch)
+        const uint32_t d = (uint32_t)(key >> shift) & mask;
+        dig[k] = d;
+        const uint64_t peers = digit_peers(d, ok[k], bits);
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        uint32_t old = 0;
+        if (ok[k] && rank == 0) {                       // lowest lane of each digit group
+            old = mycnt[d];
+            mycnt[d] = old + (uint32_t)__popcll(peers);
+        }
+        const int leader = ok[k] ? __ffsll((unsigned long long)peers) - 1 : 0;
+        old = __shfl(old, leader, 64);
+        lrank[k] = old + rank;
+    }
+    __syncthreads();
+
+    // per digit: exclusive prefix over waves, digit totals
+    uint64_t mytotal = 0;
+    if (threadIdx.x < bins) {
+        uint32_t run = 0;
+        for (int ww = 0; ww < PT_WAVES; ++ww) {
+            const uint32_t c = wcnt[ww * bins + threadIdx.x];
+            wcnt[ww * bins + threadIdx.x] = run;
+            run += c;
+        }
+        mytotal = run;
+    }
+    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+    if (threadIdx.x < bins) {
+        dstart[threadIdx.x] = (uint32_t)ds;
+        delta[threadIdx.x] = r.cnt[(size_t)tile * bins + threadIdx.x] - (uint32_t)ds;   // mod 2^32
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k)
+        if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
+    __syncthreads();
+
+    uint4 *out = reinterpret_cast<uint4 *>(r.out);
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t p = k * PT_BLOCK + threadIdx.x;
+        if (p < count) {
+            const uint4 v = stage[p];
+            const uint32_t d = (v.x >> shift) & mask;
+            const uint32_t dst = delta[d] + p;
+            out[dst] = v;
+        }
+    }
+}
+
+// Intermediate tuple of the two-pass partition when row ids fit 32 bits: {key, u32 row id}, 12 bytes.
+// Every row id the reference puts into a relation is an index below the relation's size
+// (inter_res.c:202,225), so this is the normal case; the ABI does not promise it, so a sample decides
+// (k_rowid_sample) and pass 1 raises row_id_overflow if a wider row id slips through (the host then
+// runs the join again with 16-byte intermediates).
+struct __attribute__((aligned(4))) Tuple12 { uint32_t klo, khi, rid; };
+
+// first and last 2048 row ids of both relations -> summary->wide_row_ids (the host cleared both words)
+__global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, int nrel, int force_wide, PlanSummary *summary)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;       // 8 workgroups: 2048 positions from each end
+    uint32_t mine = force_wide ? 1u : 0u;
+    for (int rel = 0; rel < nrel; ++rel) {
+        const RelArgs &r = rel ? r1 : r0;
+        if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32) | (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
+    }
+    if (__ballot(mine != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->wide_row_ids, 1u);
+}
+
+// ---- two-pass partition in run form (radix bits 9..15) ------------------------------------------
+// Pass 1 needs no histogram and no global offsets: every 4096-tuple tile is stably partitioned on
+// the LOW digit inside LDS and written back to the same place in the intermediate array, fully
+// coalesced, together with its run table (where each digit's run starts inside the tile) and each
+// tuple's HIGH digit as one byte.  The LSD order pass 2 must read — (low digit, tile, position) — is
+// then a sequence of runs: pass-2 tile (d, j) is the concatenation of the runs of digit d of pass-1
+// tiles [j * group, (j + 1) * group) — about 15/16 of 4096 tuples on uniform keys, any size on
+// skewed ones (processed 4096 at a time).  Histogram (from the digit bytes), scan and an LDS-staged
+// scatter over these tiles give the final array.  Compared with two offset-driven passes this drops
+// the first pass' histogram read of both relations and turns the first pass' scattered run writes
+// into streaming writes; pass 2 reads 1 KiB runs instead of a contiguous tile.
+__global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
+                                                         PlanSummary *summary)
+{
+    const bool T12 = summary->wide_row_ids == 0;          // 12-byte intermediates (workgroup-uniform)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [PT_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)PT_TILE * 16); // [PT_WAVES][bins]
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(dstart + 2 * bins);            // scan scratch
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= r.tiles) return;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint64_t beg = (uint64_t)tile * PT_TILE;
+    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+
+    for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+
+    uint4 t[PT_V];
+    bool ok[PT_V];
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
+        ok[k] = i < count;
+        if (ok[k]) t[k] = in[i];
+    }
+    __syncthreads();
+
+    uint32_t lrank[PT_V], dig[PT_V];
+    uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
+        const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
+        dig[k] = d;
+        uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
+        for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
+            const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        uint32_t old = 0;
+        if (ok[k] && rank == 0) {                       // lowest lane of each digit group
+            old = mycnt[d];
+            mycnt[d] = old + (uint32_t)__popcll(peers);
+        }
+        const int leader = ok[k] ? __ffsll((unsigned long long)peers) - 1 : 0;
+        old = __shfl(old, leader, 64);
+        lrank[k] = old + rank;
+    }
+    __syncthreads();
+
+    uint64_t mytotal = 0;
+    if (threadIdx.x < bins) {
+        uint32_t run = 0;
+        for (int ww = 0; ww < PT_WAVES; ++ww) {
+            const uint32_t c = wcnt[ww * bins + threadIdx.x];
+            wcnt[ww * bins + threadIdx.x] = run;
+            run += c;
+        }
+        mytotal = run;
+    }
+    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+    if (threadIdx.x < bins) dstart[threadIdx.x] = (uint32_t)ds;
+    if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : count);
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k)
+        if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
+    __syncthreads();
+
+    uint4 *out = reinterpret_cast<uint4 *>(r.out) + beg;
+    Tuple12 *out12 = reinterpret_cast<Tuple12 *>(r.out) + beg;
+    uint8_t *dg = r.dig_out + beg;
+    bool wide = false;
+#pragma unroll
+    for (int k = 0; k < PT_V; ++k) {
+        const uint32_t p = k * PT_BLOCK + threadIdx.x;
+        if (p < count) {
+            const uint4 v = stage[p];
+            if (T12) { out12[p] = Tuple12{v.x, v.y, v.z}; wide = wide || v.w != 0; }
+            else out[p] = v;
+            dg[p] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
+        }
+    }
+    if (T12 && __ballot(wide) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->row_id_overflow, 1u);
+}
+
+// pass-2 tile -> its runs: thread i < group describes run i (two coalesced reads of the transposed table)
+__device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint32_t i, uint32_t &phys, uint32_t &len)
+{
+    const uint32_t d = tile2 / r.groups, j = tile2 % r.groups;
+    const uint32_t t = j * r.group + i;
+    phys = 0; len = 0;
+    if (i < r.group && t < r.tiles1) {
+        const uint32_t a = r.runs[(size_t)d * r.tiles1 + t], b = r.runs[(size_t)(d + 1) * r.tiles1 + t];
+        len = b - a;
+        phys = t * (uint32_t)PT_TILE + a;
+    }
+}
+
+// cnt[tile2][digit] of pass 2 from the digit bytes pass 1 wrote.  One WAVE per pass-2 tile, no
+// workgroup barrier: the lanes hold the run table, every run is one 64-byte load of the whole wave,
+// sixteen runs' loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
+// chain of dependent latencies: 6 us per tile, 0.32 ms for 100M + 100M tuples.)
+constexpr int HR_BLOCK = 256;
+__global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits)
+{
+    extern __shared__ uint32_t lds_u32[];
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t bins = 1u << bits;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *h = lds_u32 + w * bins;                 // this wave's histogram
+    const uint32_t stride = gridDim.x * (HR_BLOCK / WAVE);
+    for (uint32_t tile2 = blockIdx.x * (HR_BLOCK / WAVE) + w; tile2 < r.tiles; tile2 += stride) {
+        for (uint32_t b = lane; b < bins; b += WAVE) h[b] = 0;
+        for (uint32_t c0 = 0; c0 < r.group; c0 += WAVE) {
+            uint32_t phys, len;
+            pt_run_of(r, tile2, c0 + lane, phys, len);
+            const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
+            for (uint32_t q0 = 0; q0 < nrun; q0 += 16) {
+                uint32_t dg[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)phys, (int)((q0 + q) & 63u));
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)((q0 + q) & 63u));
+                    dg[q] = (q0 + q < nrun && lane < l) ? r.dig_in[p + lane] : 0xffffffffu;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (dg[q] != 0xffffffffu) atomicAdd(&h[dg[q]], 1u);
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)((q0 + q) & 63u));
+                    if (q0 + q < nrun && l > WAVE) {          // skewed keys: a run longer than one load
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)phys, (int)((q0 + q) & 63u));
+                        for (uint32_t e = lane + WAVE; e < l; e += WAVE) atomicAdd(&h[r.dig_in[p + e]], 1u);
+                    }
+                }
+            }
+        }
+        uint32_t *row = r.cnt + (size_t)tile2 * bins;
+        for (uint32_t b = lane; b < bins; b += WAVE) row[b] = h[b];
+    }
+}
+
+// bucket histogram of the full radix = column sums of pass 2's counts per pass-1 digit
+// (grid: pass-1 digits x relations; 1024 threads = digits x slices of the tile groups)
+__global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
+{
+    __shared__ uint32_t part[1024];
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t bins = 1u << bits, d = blockIdx.x;
+    const uint32_t b = threadIdx.x & (bins - 1u), slice = threadIdx.x >> bits, slices = 1024u >> bits;
+    uint32_t s = 0;
+    const uint32_t *base = r.cnt + (size_t)d * r.groups * bins + b;
+#pragma unroll 4
+    for (uint32_t j = slice; j < r.groups; j += slices) s += base[(size_t)j * bins];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < bins) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < slices; ++q) t += part[q * bins + threadIdx.x];
+        full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)] = t;
+    }
+}
+
+// T12: 12-byte intermediates in; O12: 12-byte tuples out too (the join's own partition when the row ids fit 32 bits:
+// the fused kernel then streams and gathers 12 instead of 16 bytes per tuple; rhj_partition_device() hands out
+// rhj_tuple and keeps 16-byte output).  (A run-time switch here cost 30 %: compiled apart, launched side by side.)
+#ifndef SR_VN
+#define SR_VN 8         // tuples per thread and batch of pass 2 (the batch is independent of pass 1's 4096-tuple tiles)
+#endif
+#ifndef SR_MINW
+#define SR_MINW 4
+#endif
+constexpr int SR_V = SR_VN;
+constexpr int SR_TILE = PT_BLOCK * SR_V;
+template <bool T12, bool O12>
+__global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
+                                                           const PlanSummary *summary)
+{
+    if ((summary->wide_row_ids == 0) != T12) return;      // the other instantiation's launch moves the data
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [SR_TILE]
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)SR_TILE * 16); // [PT_WAVES][bins]
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint32_t *delta = dstart + bins;                                           // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(delta + bins);                 // scan scratch [PT_BLOCK / 64 + 1]
+    uint32_t *gbase = reinterpret_cast<uint32_t *>(sm + PT_BLOCK / 64 + 2);    // [bins] next output position per digit
+    uint32_t *runoff = gbase + bins;                                           // [PT_MAX_GROUP + 1] first element of run i
+    uint32_t *rbase = runoff + PT_MAX_GROUP + 1;                               // [PT_MAX_GROUP] physical index of element e of run i = rbase[i] + e
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in);
+    uint4 *out = reinterpret_cast<uint4 *>(r.out);
+
+    // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx.x % 8), each with its own L2.
+    // Consecutive pass-2 tiles write ADJACENT pieces of every digit's output, so the cache line at the
+    // seam is completed by the neighbour tile: the tiles are dealt to the XCDs in blocks of as many
+    // consecutive tiles as an XCD has workgroups, which walk the block together — both halves of a seam
+    // line meet in the same L2 and leave as one full-line write (-6 % against a plain grid stride) — and
+    // the blocks go round-robin over the XCDs, so that the oversized tiles of a hot digit (Zipf keys) are
+    // shared by all of them (-5 % on 100M x 1B against one contiguous eighth per XCD; same on uniform
+    // keys).  The next tile's run table and output offsets are fetched while the current tile is moved.
+    const uint32_t xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;           // gridDim.x is a multiple of 8
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t tstep = 8u * per_xcd;                                        // the next block of this XCD
+    const uint32_t t_end = r.tiles;
+    const uint32_t t_first = xcd * per_xcd + slot;
+    uint32_t nphys = 0, nlen = 0, ngb = 0;
+    if (t_first < t_end) {
+        pt_run_of(r, t_first, threadIdx.x, nphys, nlen);
+        if (threadIdx.x < bins) ngb = r.cnt[(size_t)t_first * bins + threadIdx.x];
+    }
+    for (uint32_t tile2 = t_first; tile2 < t_end; tile2 += tstep) {
+    uint32_t total;
+    {
+        const uint32_t phys = nphys, len = nlen;
+        uint64_t tot64;
+        const uint32_t off = (uint32_t)block_excl_scan<PT_BLOCK>(len, &tot64, sm);
+        total = (uint32_t)tot64;
+        if (threadIdx.x < PT_MAX_GROUP) { runoff[threadIdx.x] = threadIdx.x < r.group ? off : total; rbase[threadIdx.x] = phys - off; }
+        if (threadIdx.x == 0) runoff[PT_MAX_GROUP] = total;
+        if (threadIdx.x < bins) gbase[threadIdx.x] = ngb;
+        const uint32_t nt = tile2 + tstep;
+        nphys = 0; nlen = 0;
+        if (nt < t_end) {
+            pt_run_of(r, nt, threadIdx.x, nphys, nlen);
+            if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t sb = 0; sb < total; sb += SR_TILE) {
+        const uint32_t count = min((uint32_t)SR_TILE, total - sb);
+        for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+
+        uint4 t[SR_V];
+        bool ok[SR_V];
+        uint32_t pos = 0;                             // last run that starts at or before the element
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            const uint32_t i = w * (WAVE * SR_V) + k * WAVE + lane;
+            ok[k] = i < count;
+            const uint32_t e = sb + i;
+            if (k == 0) {
+                for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
+                    if (runoff[pos + s2] <= e) pos += s2;
+            } else {
+                // 64 elements further on: usually the next run or the one after it
+                if (runoff[pos + 1] <= e) ++pos;
+                if (runoff[pos + 1] <= e) ++pos;
+                if (runoff[pos + 1] <= e) {           // short or empty runs in between: search again
+                    pos = 0;
+                    for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
+                        if (runoff[pos + s2] <= e) pos += s2;
+                }
+            }
+            if (ok[k]) {
+                if (T12) { const Tuple12 x = reinterpret_cast<const Tuple12 *>(r.in)[rbase[pos] + e]; t[k] = make_uint4(x.klo, x.khi, x.rid, 0u); }
+                else t[k] = in[rbase[pos] + e];
+            }
+        }
+        __syncthreads();
+
+        uint32_t lrank[SR_V], dig[SR_V];
+        uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;
+            const uint32_t d = (uint32_t)(key >> shift) & mask;
+            dig[k] = d;
+            const uint64_t peers = digit_peers(d, ok[k], bits);
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            uint32_t old = 0;
+            if (ok[k] && rank == 0) {
+                old = mycnt[d];
+                mycnt[d] = old + (uint32_t)__popcll(peers);
+            }
+            const int leader = ok[k] ? __ffsll((unsigned long long)peers) - 1 : 0;
+            old = __shfl(old, leader, 64);
+            lrank[k] = old + rank;
+        }
+        __syncthreads();
+
+        uint64_t mytotal = 0;
+        if (threadIdx.x < bins) {
+            uint32_t run = 0;
+            for (int ww = 0; ww < PT_WAVES; ++ww) {
+                const uint32_t c = wcnt[ww * bins + threadIdx.x];
+                wcnt[ww * bins + threadIdx.x] = run;
+                run += c;
+            }
+            mytotal = run;
+        }
+        const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+        if (threadIdx.x < bins) {
+            dstart[threadIdx.x] = (uint32_t)ds;
+            const uint32_t gb = gbase[threadIdx.x];
+            delta[threadIdx.x] = gb - (uint32_t)ds;                 // mod 2^32
+            gbase[threadIdx.x] = gb + (uint32_t)mytotal;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k)
+            if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
+        __syncthreads();
+
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            const uint32_t p = k * PT_BLOCK + threadIdx.x;
+            if (p < count) {
+                const uint4 v = stage[p];
+                const uint32_t d = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> shift) & mask;
+                if (O12) reinterpret_cast<Tuple12 *>(r.out)[delta[d] + p] = Tuple12{v.x, v.y, v.z};
+                else out[delta[d] + p] = v;
+            }
+        }
+        __syncthreads();
+    }
+    }   // grid-stride loop
+}
+
+}  // namespace rhj
