@@ -37,6 +37,8 @@ WORKLOADS = {
     "c2": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="uniform", name="1Mx1M uniform u64 FK, 8 radix bits"),
     "c3": dict(nR=100_000_000, nS=100_000_000, bits=12, dist="uniform", name="100Mx100M uniform u64 FK, 12 radix bits"),
     "c4": dict(nR=100_000_000, nS=1_000_000_000, bits=14, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 14 radix bits (config leaves the radix free: 6.1 K build tuples per bucket fit LDS)"),
+    "c4b12": dict(nR=100_000_000, nS=1_000_000_000, bits=12, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 12 radix bits (experiment)"),
+    "c4b13": dict(nR=100_000_000, nS=1_000_000_000, bits=13, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 13 radix bits (experiment)"),
     "c4b15": dict(nR=100_000_000, nS=1_000_000_000, bits=15, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 15 radix bits"),
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
     "c3b13": dict(nR=100_000_000, nS=100_000_000, bits=13, dist="uniform", name="100Mx100M uniform u64 FK, 13 radix bits (experiment)"),
@@ -463,18 +465,22 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_%s_pmc.json" % args.workload)))
+            pat = "r*_%s_subsplit_pmc.json" if sub else "r*_%s_pmc.json"
+            cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pat % args.workload)) if sub or "subsplit" not in f)
             if cands and (fused or sub):
                 pm = json.load(open(cands[-1]))
+                want = ("k_sub_join", "k_sub_bscan", "k_sub_emit") if sub else ("k_join_fused",)
+                per = {}
                 for kname, kv in pm.items():
-                    if "k_join_fused" in kname and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
-                        t = int((kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024)
-                        if traffic is not None and t <= traffic:
-                            continue                      # the instantiation that returned at once (other stash width)
-                        traffic = t
-                        traffic_src = ("%s: FETCH_SIZE + WRITE_SIZE of the last dispatch, uncorrected (8 B/lane key streams and "
-                                       "16 B divergent gathers are not the calibrated 16 B/lane streaming case of the guide)"
-                                       % os.path.basename(cands[-1]))
+                    if isinstance(kv, dict) and any(wk in kname for wk in want) and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
+                        key = [wk for wk in want if wk in kname][0]
+                        per[key] = max(per.get(key, 0), int((kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024))   # max: the instantiation that ran
+                if per:
+                    traffic = sum(per.values())
+                    traffic_src = ("%s (collected at git head %s; not measured in this run: counters cannot be read from inside the "
+                                   "process): FETCH_SIZE + WRITE_SIZE of the last dispatch, uncorrected — FETCH_SIZE counts half the bytes "
+                                   "of 16 B/lane streaming reads (guide), 8-12 B/lane streams and divergent gathers are uncalibrated"
+                                   % (os.path.basename(cands[-1]), pm.get("_collected_at_git_head", "unknown")))
         except Exception:
             traffic, traffic_src = None, None
         res = {

@@ -691,7 +691,7 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     const size_t desc_bytes = (size_t)nsub * sizeof(SjDesc), bdesc_bytes = (size_t)bins * sizeof(SjBucket);
     if (ensure(g.summary, sizeof(PlanSummary) + sizeof(SjSummary)) || ensure(g.sjunits, desc_bytes + bdesc_bytes + extra_cap * sizeof(SjExtra)) ||
         ensure(g.btotal, (size_t)2 * bins * 8) || ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
-        ensure(g.arena, arena_cap * 4))
+        ensure(g.arena, arena_cap * 4 + 64))
         return -1;
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
     SjSummary *dsj = (SjSummary *)(dsum + 1);

@@ -1,18 +1,28 @@
 #!/bin/bash
 # tools/collect_profiles.sh <tag> — bench lines, rocprofv3 kernel stats and FETCH/WRITE counters of one build
 tag=$1
+head=${2:-unknown}      # git head of the build (the GPU box has no .git): tools/collect_profiles.sh <tag> $(git rev-parse --short HEAD)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > gpurun_out/${tag}_c3_bench.json 2> gpurun_out/${tag}_c3_bench.err
 echo "c3 bench done"
-python3 bench.py --workload c2 --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/${tag}_c2_bench.json 2>/dev/null
+python3 bench.py --workload c2 --steps 200 --warmup 20 > gpurun_out/${tag}_c2_bench.json 2>/dev/null
 python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c4_bench.json 2>/dev/null
-echo "c2 c4 bench done"
+python3 bench.py --workload c3 --scaling strong --steps 5 --warmup 2 > gpurun_out/${tag}_c3_strong_1gpu.json 2>/dev/null
+RHJ_SUB=1 python3 bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_c3_subsplit_bench.json 2>/dev/null
+echo "c2 c4 strong subsplit bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
 cp $(ls gpurun_out/${tag}_prof/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_c3_kernel_stats.csv
+RHJ_SUB=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_sub -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_prof_sub.log 2>&1
+cp $(ls gpurun_out/${tag}_prof_sub/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_c3_subsplit_kernel_stats.csv
 echo "kernel stats done"
 bash tools/pmc.sh ${tag} "FETCH_SIZE" "WRITE_SIZE" -- --steps 3 --warmup 2 --no-cpu-baseline
-python3 tools/pmc_summary.py ${tag} > /dev/null
+python3 tools/pmc_summary.py ${tag} $head > /dev/null
 cp gpurun_out/pmc_${tag}.json gpurun_out/${tag}_c3_pmc.json
+RHJ_SUB=1 bash tools/pmc.sh ${tag}s "FETCH_SIZE" "WRITE_SIZE" -- --steps 3 --warmup 2 --no-cpu-baseline
+python3 tools/pmc_summary.py ${tag}s $head > /dev/null
+cp gpurun_out/pmc_${tag}s.json gpurun_out/${tag}_c3_subsplit_pmc.json
 python3 tools/filter_bench.py > gpurun_out/${tag}_filter.json 2>/dev/null || echo "filter bench failed"
+python3 tools/host_rate.py > gpurun_out/${tag}_host_rate.json 2>/dev/null || echo "host rate failed"
+python3 tools/small_e2e.py > gpurun_out/${tag}_small_e2e.json 2>/dev/null || echo "small e2e failed"
 echo "all done"

@@ -15,6 +15,10 @@ for d in sorted(glob.glob("gpurun_out/pmc_%s_*/" % tag)):
         for (k, c), (v, ns) in last.items():
             out[k][c] = v
             out[k]["ns"] = ns
+if len(sys.argv) > 2:
+    out["_collected_at_git_head"] = sys.argv[2]
 json.dump(out, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1)
 for k, v in out.items():
+    if not isinstance(v, dict):
+        continue
     print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})
