@@ -340,6 +340,11 @@ struct FjGather {
     __device__ __forceinline__ uint4 load(uint32_t pos) const
     {
         if (N32) {
+#ifdef FJ_ABL_G8          // timing experiment only (wrong results): 8-byte gathers from a third less memory
+            typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+            const v2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(pos * 8u), 0, 16 /* sc1 */);
+            return make_uint4(w.x, w.y, w.x, 0u);
+#endif
             typedef uint32_t v3 __attribute__((ext_vector_type(3)));
             const v3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(pos * 12u), 0, 16 /* sc1 */);
             return make_uint4(v.x, v.y, v.z, 0u);
@@ -390,7 +395,11 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather<
         bool ex[FJ_V];
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
+#ifdef FJ_ABL_G8
+            const bool eq = pos[k] != 0xffffffffu && (g[k].x | 1u) != 0u;          // every tag hit counts (timing only)
+#else
             const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
+#endif
             if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
             ex[k] = OVF && eq && c[k] != 0;
             c[k] += eq;
