@@ -663,7 +663,7 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     for (int i = 0; i < 2; ++i) {
         const uint32_t tiles1 = tiles_for(n[i]);
         const uint32_t groups = (tiles1 + group - 1) / group;
-        if (ensure(*tmpb[i], n[i] * 12 + 64) || ensure(*partb[i], n[i] * 12 + 64) || ensure(*digb[i], n[i] + 64) ||
+        if (ensure(*tmpb[i], n[i] * 16 + 64) /* pass 1 writes 16-byte tuples when the sample finds wide row ids */ || ensure(*partb[i], n[i] * 12 + 64) || ensure(*digb[i], n[i] + 64) ||
             ensure(*runb[i], (size_t)tiles1 * (bins1 + 1) * 2 + 64) || ensure(*cntb[i], (size_t)bins1 * groups * D * 4) ||
             ensure(*sqb[i], n[i] + 64) || ensure(*segb[i], (size_t)2 * bins1 * D * 4))
             return -1;

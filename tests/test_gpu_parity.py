@@ -393,13 +393,16 @@ def test_entry_points_from_several_host_threads(rhj, oracle):
     (12, 500_000, 500_000, "dups", 40_000),     # ~12 per key: more matches than the arena holds -> falls back
     (13, 200_000, 2_000_000, "zipf", 0),        # skewed probe side: spans of a long probe side, multi-step K2
     (12, 150_000, 150_000, "dups", 300),        # 500 duplicates per key: counts above 254, build sides above the LDS cap -> falls back
+    (12, 400_000, 400_000, "wide", 0),          # row ids of 2^40 and more: pass 1 keeps 16-byte tuples -> falls back
 ])
 def test_subsplit_path_matches_oracle(rhj, oracle, bits, nR, nS, kind, dom):
     """The sub-split path (csrc/rhj_subjoin.hip.h; opt-in) against the oracle, bit for bit, and that it is the path
     that ran (rhj_stats.reserved) — or that it handed the join to the fused path where its plan has to refuse."""
     rhj.set_bits(bits)
-    if kind == "fk":
+    if kind in ("fk", "wide"):
         R, S = oracle.generate(nR, 0, 0, 0.0, 71), oracle.generate(nS, 1, nR, 0.0, 72)
+        if kind == "wide":
+            R["row_id"] += np.uint64(1) << np.uint64(40)
     elif kind == "zipf":
         R, S = oracle.generate(nR, 0, 0, 0.0, 73), oracle.generate(nS, 2, nR, 0.9, 74)
     else:
@@ -416,6 +419,6 @@ def test_subsplit_path_matches_oracle(rhj, oracle, bits, nR, nS, kind, dom):
     finally:
         rhj.lib.rhj_set_subsplit(0)
     assert m == len(want) and np.array_equal(got, want), (bits, kind, path)
-    assert path == ("fused" if dom in (300, 40_000) else "subsplit"), path
+    assert path == ("fused" if dom in (300, 40_000) or kind == "wide" else "subsplit"), path
     t, m = rhj.join_device(dR, dS)                                   # and the default path on the same inputs
     assert rhj.stats()["path"] != "subsplit" and np.array_equal(rhj.pairs_to_numpy(t), want)
