@@ -422,3 +422,37 @@ def test_subsplit_path_matches_oracle(rhj, oracle, bits, nR, nS, kind, dom):
     assert path == ("fused" if dom in (300, 40_000) or kind == "wide" else "subsplit"), path
     t, m = rhj.join_device(dR, dS)                                   # and the default path on the same inputs
     assert rhj.stats()["path"] != "subsplit" and np.array_equal(rhj.pairs_to_numpy(t), want)
+
+
+def test_threads_on_the_second_device_when_there_is_one(oracle):
+    """HIP's current device is per thread: with the library on device 1, calls from threads that never touched HIP
+    must still allocate and launch there (every entry point selects the library's device).  Needs two visible GPUs:
+    skipped on a one-GPU box.  Own process: one library context per process."""
+    import subprocess, sys, torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    code = r'''
+import importlib, sys, threading
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "oracle")
+from pyoracle import Oracle
+mod = importlib.import_module("sigmod-2018_amd")
+o = Oracle(); rhj = mod.RHJ(device=1); rhj.set_bits(12)
+R = o.generate(50000, 0, 0, 0.0, 5); S = o.generate(120000, 1, 50000, 0.0, 6); want = o.join(R, S, 12)
+bad = []
+def run():
+    for _ in range(6):
+        got = rhj.RadixHashJoin(R, S)
+        if len(got) != len(want) or not (got == want).all(): bad.append(1)
+ts = [threading.Thread(target=run) for _ in range(4)]
+[t.start() for t in ts]; [t.join() for t in ts]
+try:
+    mod.RHJ(device=0)
+    bad.append("second context on another device was not refused")
+except RuntimeError:
+    pass
+print("BAD" if bad else "OK", bad)
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip().startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])
