@@ -2,6 +2,7 @@
 against the oracle on the same seeded inputs and against the committed golden vectors
 (bit-exact: integer / index work)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
