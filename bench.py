@@ -46,6 +46,9 @@ WORKLOADS = {
     "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
     # BASELINE configs[4]: the SIGMOD'18 `small` workload through the reference's own driver and query executor
     # linked against librhj.so (device-resident configuration); the 50 queries are dealt round-robin to the ranks
+    # the 88 RadixHashJoin calls of the `small` workload (inputs recorded at the boundary, tests/golden) as independent
+    # joins of a plan: dealt to the ranks largest first (shard.assign_joins), every match list sent to all ranks
+    "smalljoins": dict(name="SIGMOD'18 small workload: its 88 RadixHashJoin calls (recorded inputs, 4 radix bits) dealt to the ranks as independent joins"),
     "small": dict(name="SIGMOD'18 small workload (14 relations, 50 queries), reference driver + librhj.so, queries sharded over the ranks"),
 }
 
@@ -280,6 +283,55 @@ def run_small(args, world, rank, local, dist):
         print(json.dumps(res))
 
 
+def run_smalljoins(args, rhj, world, rank, backend, dist):
+    """Independent joins of a plan over the ranks (shard.run_independent_joins): the 88 joins of `small`, every pair list
+    checked against the digest the compiled reference produced for it (tests/golden/small_boundary.json)."""
+    import torch
+    for p in (os.path.join(HERE, "tests"), os.path.join(HERE, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import helpers
+    from pyoracle import Oracle
+    shard = importlib.import_module("sigmod-2018_amd.shard")
+    g = helpers.Golden()
+    ops = shard.RhjOps(rhj)
+    recs = g.small["joins"]
+    joins = [tuple(rhj.to_device(x) for x in g.small_join(j["idx"])) for j in recs]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = owner = None
+    for _ in range(args.warmup):
+        res, owner = shard.run_independent_joins(ops, joins, 4)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, owner = shard.run_independent_joins(ops, joins, 4)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rhj.dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    o = Oracle()
+    for r, j in zip(res, recs):                            # every rank holds every list (gathered): all of them check
+        helpers.assert_digest(o, rhj.pairs_to_numpy(r), j, "small join %d" % j["idx"])
+    if rank == 0:
+        tuples = sum(int(a.shape[0]) + int(b.shape[0]) for a, b in joins)
+        load = [sum(int(a.shape[0]) + int(b.shape[0]) for (a, b), ow in zip(joins, owner) if ow == r) for r in range(world)]
+        print(json.dumps({"metric": "joins/s on the 88 RadixHashJoin calls of the SIGMOD'18 small workload", "value": len(joins) * args.steps / elapsed,
+                          "unit": "joins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "SIGMOD'18 small (fixture)",
+                          "config": {"workload": WORKLOADS["smalljoins"]["name"], "id": "smalljoins", "joins": len(joins), "input_tuples": tuples,
+                                     "pairs": sum(j["matches"] for j in recs), "parallelism": "independent joins dealt largest first over %d rank(s), "
+                                     "all-gather-v of every match list" % world, "input_tuples_per_rank": load,
+                                     "answers": "every pair list equals the reference's digest"},
+                          "roofline": None}))
+
+
 def run_strong(args, w, rhj, world, rank, backend, dist):
     """ONE join of the workload sharded over the ranks by bucket range: the relations are replicated
     (same seed on every rank: a device-resident column store per GPU), every rank histograms both, selects the tuples
@@ -376,6 +428,11 @@ def main():
     w = WORKLOADS[args.workload]
     mod = importlib.import_module("sigmod-2018_amd")
     rhj = mod.RHJ(device=local)
+    if args.workload == "smalljoins":
+        run_smalljoins(args, rhj, world, rank, backend, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     rhj.set_bits(w["bits"])
     if args.force_hbm_table:
         rhj.lib.rhj_set_force_hbm_table(1)

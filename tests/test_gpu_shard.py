@@ -116,3 +116,21 @@ def test_select_capacity_and_empty_ranges(rhj, oracle):
     assert torch.equal(out, dR)
     assert lib.rhj_select_bucket_range_device(dR.data_ptr(), 10000, 0, 64, out.data_ptr(), 100, C.byref(got)) == 1 and got.value == 10000
     assert lib.rhj_select_bucket_range_device(dR.data_ptr(), 0, 0, 64, out.data_ptr(), 100, C.byref(got)) == 0 and got.value == 0
+
+
+def test_small_workload_joins_as_independent_joins_of_a_plan(rhj, shard, oracle, golden, nccl_world):
+    """shard.run_independent_joins over the 88 RadixHashJoin calls of `small` (recorded inputs): dealt with assign_joins,
+    run through rhj_join_device, gathered; every pair list against the digest of the compiled reference."""
+    import helpers
+    ops = shard.RhjOps(rhj)
+    recs = golden.small["joins"]
+    joins = [tuple(rhj.to_device(x) for x in golden.small_join(j["idx"])) for j in recs]
+    res, owner = shard.run_independent_joins(ops, joins, 4)
+    assert len(res) == 88 and set(owner) == {0}
+    for r, j in zip(res, recs):
+        helpers.assert_digest(oracle, rhj.pairs_to_numpy(r), j, "small join %d" % j["idx"])
+    # the same deal for 8 ranks: balanced within the largest join, nothing lost
+    sizes = [j["nR"] + j["nS"] for j in recs]
+    own8 = shard.assign_joins(sizes, 8)
+    load = [sum(s for s, o in zip(sizes, own8) if o == r) for r in range(8)]
+    assert sorted(set(own8)) == list(range(8)) and max(load) - min(load) <= max(sizes)
