@@ -715,7 +715,7 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     sa.arena = (uint32_t *)g.arena.p; sa.arena_cap = arena_cap;
     sa.btotal = (unsigned long long *)g.btotal.p; sa.obase = (uint64_t *)g.btotal.p + bins;
     sa.out = out; sa.out_capacity = out ? out_capacity : 0;
-    sa.nR = nR; sa.g = geo; sa.max_bucket = SE_MAXCH * SE_CHUNK < 65535u ? SE_MAXCH * SE_CHUNK : 65535u;     // k_sub_emit2: u16 places inside a bucket's sub-lists
+    sa.nR = nR; sa.g = geo; sa.max_bucket = 1u << 20;
 
     HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
     RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, p1[0], p1[1], 2, 0, dsum);
@@ -746,11 +746,7 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
     RHJ_LAUNCH(k_sub_bscan, dim3(1), dim3(1024), 0, g.stream, sa);
     HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
-    if (out) {
-        static const int emit2 = getenv("RHJ_SUB_EMIT1") ? 0 : 1;          // RHJ_SUB_EMIT1=1: the first form (A/B runs)
-        if (emit2) RHJ_LAUNCH(k_sub_emit2, dim3(bins), dim3(SE_BLOCK), se2_lds_bytes(geo.kb), g.stream, sa);
-        else RHJ_LAUNCH(k_sub_emit, dim3(bins), dim3(SE_BLOCK), 0, g.stream, sa);
-    }
+    if (out) RHJ_LAUNCH(k_sub_emit, dim3(bins), dim3(SE_BLOCK), 0, g.stream, sa);
     HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
     struct Back { PlanSummary p; SjSummary s; } *hb = (Back *)g.pin;
     HIP_TRY(hipMemcpyAsync(hb, g.summary.p, sizeof(Back), hipMemcpyDeviceToHost, g.stream));

@@ -892,187 +892,4 @@ __global__ __launch_bounds__(SE_BLOCK) void k_sub_emit(SjArgs a)
     }
 }
 
-// ---- K2, second form: one workgroup per bucket sweeps it chunk by chunk, no barrier inside a sweep --------------------
-// Three sweeps over the bucket, two barriers per BUCKET (k_sub_emit has two per 1024 positions); consecutive chunks go
-// to consecutive waves, so the workgroup as a whole walks the bucket — and writes its pairs — front to back:
-//   A  per chunk and sub-bucket: how many of the chunk's positions came from it (k ballots per 64 positions)
-//      -> scanned down the chunks: where in each sub-list every chunk starts
-//   B  per chunk: its positions' places in the sub-lists -> their match counts from the stash -> the chunk's matches
-//      -> scanned: where in the output every chunk starts
-//   C  per chunk: stash row (+ arena) -> pairs
-// sseq is read three times and the count bytes twice (both L2-resident: 25 KB per bucket).
-#ifndef SE_ABL
-#define SE_ABL 0        // timing experiments only (wrong results): 1 no pair stores, 2 no stash-row gathers, 3 no count gathers, 4 nt stores
-#endif
-#ifndef SE_CHUNK_ROUNDS
-#define SE_CHUNK_ROUNDS 4
-#endif
-constexpr int SE_RPC = SE_CHUNK_ROUNDS;               // rounds of 64 positions per chunk
-constexpr uint32_t SE_CHUNK = SE_RPC * WAVE;
-constexpr uint32_t SE_MAXCH = 1024;                   // chunks per bucket at most (longer probe sides fall back)
-__host__ __device__ constexpr size_t se2_lds_bytes(int kb) { return (size_t)SE_MAXCH * ((2u << kb) + 8u); }   // u16 counts, u64 bases
-
-__device__ __forceinline__ void se_store(uint4 *p, uint4 v)
-{
-#if SE_ABL == 4
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4 *>(p));
-#else
-    *p = v;
-#endif
-}
-
-// places of one round's 64 positions in their sub-lists; carry (lanes < S) moves on
-__device__ __forceinline__ uint32_t se_places(uint32_t sq, int kb, uint32_t lane, uint64_t lt, uint32_t S, uint32_t &carry)
-{
-    const bool ok = sq != 0xffu;
-    uint64_t peers = __ballot(ok), mineS = peers;
-    for (int bit = 0; bit < kb; ++bit) {
-        const uint64_t m = __ballot(ok && ((sq >> bit) & 1u));
-        peers &= ((sq >> bit) & 1u) ? m : ~m;
-        mineS &= ((lane >> bit) & 1u) ? m : ~m;
-    }
-    const uint32_t q = __shfl(carry, ok ? (int)sq : 0, 64) + (uint32_t)__popcll(peers & lt);
-    if (lane < S) carry += (uint32_t)__popcll(mineS);
-    return q;
-}
-
-__global__ __launch_bounds__(SE_BLOCK) void k_sub_emit2(SjArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t se_lds[];
-    __shared__ uint32_t s_base[32];
-    if (!sj_usable(a)) return;
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t S = 1u << a.g.kb;
-    const uint32_t b = blockIdx.x;
-    const SjBucket bd = a.bdesc[b];
-    const uint32_t np = bd.np;
-    if (np == 0) return;
-    const uint32_t nch = (np + SE_CHUNK - 1u) / SE_CHUNK;
-    uint64_t *mt = reinterpret_cast<uint64_t *>(se_lds);                        // [SE_MAXCH] matches per chunk -> first output position
-    uint16_t *sh = reinterpret_cast<uint16_t *>(mt + SE_MAXCH);                 // [nch][S] positions per chunk and sub-bucket -> prefix
-    const bool flip = bd.flip != 0;
-    const uint8_t *sseq = (flip ? a.sseqS : a.sseqR) + bd.p0;
-    const uint8_t *scnt = a.stash_cnt + (flip ? a.nR : 0);
-    const uint2 *srow = a.stash_row + (flip ? a.nR : 0);
-    uint4 *out = reinterpret_cast<uint4 *>(a.out);
-    const uint64_t cap = a.out_capacity;
-    const uint64_t lt = lanemask_lt();
-
-    // ---- A
-    for (uint32_t c = w; c < nch; c += SE_WAVES) {
-        uint32_t sq[SE_RPC];
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) { const uint32_t p = c * SE_CHUNK + r * WAVE + lane; sq[r] = p < np ? sseq[p] : 0xffu; }
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) {
-            const bool ok = sq[r] != 0xffu;
-            uint64_t mineS = __ballot(ok);
-            for (int bit = 0; bit < a.g.kb; ++bit) {
-                const uint64_t m = __ballot(ok && ((sq[r] >> bit) & 1u));
-                mineS &= ((lane >> bit) & 1u) ? m : ~m;
-            }
-            cnt += (uint32_t)__popcll(mineS);
-        }
-        if (lane < S) sh[c * S + lane] = (uint16_t)cnt;                       // <= SE_CHUNK
-    }
-    if (threadIdx.x < S) s_base[threadIdx.x] = a.desc[(b << a.g.kb) | threadIdx.x].probe_off;
-    __syncthreads();
-    if (threadIdx.x < S) {                             // down the chunks: positions of sub-list s in front of chunk c (< 2^16: a
-        uint32_t run = 0;                              // bucket has at most SE_MAXCH * SE_CHUNK positions... kept below 65536)
-        for (uint32_t c = 0; c < nch; ++c) { const uint32_t v = sh[c * S + threadIdx.x]; sh[c * S + threadIdx.x] = (uint16_t)run; run += v; }
-    }
-    __syncthreads();
-
-    // ---- B
-    for (uint32_t c = w; c < nch; c += SE_WAVES) {
-        uint32_t carry = lane < S ? s_base[lane] + sh[c * S + lane] : 0;
-        uint32_t sq[SE_RPC], q[SE_RPC], cc[SE_RPC];
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) { const uint32_t p = c * SE_CHUNK + r * WAVE + lane; sq[r] = p < np ? sseq[p] : 0xffu; }
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) q[r] = se_places(sq[r], a.g.kb, lane, lt, S, carry);
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) cc[r] = sq[r] != 0xffu ? (SE_ABL == 3 ? (q[r] & 1u) : scnt[q[r]]) : 0;
-        uint32_t mine = 0;
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) {
-            if (cc[r] == 255u) cc[r] = a.arena[srow[q[r]].x];                // rare: the count heads the arena run
-            mine += cc[r];
-        }
-        uint32_t tot;
-        wave_excl_scan_u32(mine, &tot);
-        if (lane == 0) mt[c] = tot;
-    }
-    __syncthreads();
-    if (w == 0) {                                      // down the chunks: first output position of chunk c
-        uint64_t run = a.obase[b];
-        for (uint32_t c0 = 0; c0 < nch; c0 += WAVE) {
-            const uint32_t c = c0 + lane;
-            const uint64_t v = c < nch ? mt[c] : 0;
-            uint64_t x = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d, 64); if ((int)lane >= d) x += y; }
-            if (c < nch) mt[c] = run + x - v;
-            run += __shfl(x, 63, 64);
-        }
-    }
-    __syncthreads();
-
-    // ---- C
-    for (uint32_t c = w; c < nch; c += SE_WAVES) {
-        uint32_t carry = lane < S ? s_base[lane] + sh[c * S + lane] : 0;
-        uint64_t wat = mt[c];
-        uint32_t sq[SE_RPC], q[SE_RPC], cc[SE_RPC], rx[SE_RPC], ry[SE_RPC];
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) { const uint32_t p = c * SE_CHUNK + r * WAVE + lane; sq[r] = p < np ? sseq[p] : 0xffu; }
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) q[r] = se_places(sq[r], a.g.kb, lane, lt, S, carry);
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) {
-            const bool ok = sq[r] != 0xffu;
-            cc[r] = ok ? (SE_ABL == 3 ? (q[r] & 1u) : scnt[q[r]]) : 0;
-            const uint2 row = ok ? (SE_ABL == 2 ? make_uint2(q[r], q[r]) : srow[q[r]]) : make_uint2(0, 0);
-            rx[r] = row.x; ry[r] = row.y;
-        }
-#pragma unroll
-        for (int r = 0; r < SE_RPC; ++r) {
-            if (__ballot(cc[r] == 255u) != 0) {
-                const bool big = cc[r] == 255u;
-                const uint32_t real = big ? a.arena[rx[r]] : cc[r];
-                rx[r] += big ? 1u : 0u;
-                cc[r] = real;
-            }
-            if (__ballot(cc[r] > 1u) == 0) {            // zero or one match per tuple: offsets from one ballot
-                const uint64_t mm = __ballot(cc[r] != 0);
-                const uint64_t dst = wat + (uint32_t)__popcll(mm & lt);
-                if (SE_ABL != 1 && cc[r] != 0 && dst < cap) se_store(out + dst, sj_pair(flip, ry[r], rx[r]));
-                wat += (uint32_t)__popcll(mm);
-            } else {                                   // output-centric: see k_sub_emit
-                uint32_t t;
-                const uint32_t excl = wave_excl_scan_u32(cc[r], &t);
-                const uint32_t incl = excl + cc[r];
-                for (uint32_t o0 = 0; o0 < t; o0 += WAVE) {
-                    const uint32_t o = o0 + lane;
-                    uint32_t lo_ = 0;
-#pragma unroll
-                    for (int stp = 32; stp >= 1; stp >>= 1) {
-                        const uint32_t v = __shfl(incl, (int)(lo_ + stp - 1u), 64);
-                        if (v <= o) lo_ += stp;
-                    }
-                    const int src = (int)min(lo_, 63u);
-                    const uint32_t ci = __shfl(cc[r], src, 64), xi = __shfl(rx[r], src, 64), pi = __shfl(ry[r], src, 64), ei = __shfl(excl, src, 64);
-                    if (o < t) {
-                        const uint32_t brid = ci == 1u ? xi : a.arena[xi + (o - ei)];
-                        const uint64_t dst = wat + o;
-                        if (SE_ABL != 1 && dst < cap) se_store(out + dst, sj_pair(flip, pi, brid));
-                    }
-                }
-                wat += t;
-            }
-        }
-    }
-}
-
 }  // namespace rhj
