@@ -156,6 +156,10 @@ void rhj_set_resident(int on);
  * sub-bucket's build side is LDS-resident and no candidate is gathered from memory (csrc/rhj_subjoin.hip.h);
  * 0 (default): the fused / tiled paths.  Results are identical either way (env RHJ_SUB=1). */
 void rhj_set_subsplit(int on);
+/* 1 (default): a join on at most 8 radix bits whose relations hold at most ~8 M tuples together runs histogram,
+ * scan, plan, scatter and the fused join as the phases of ONE kernel launch (csrc/rhj_small.hip.h); 0: the same
+ * steps as separate launches.  Results are identical either way (env RHJ_NO_SMALL=1). */
+void rhj_set_small(int on);
 
 /* ---- device-resident entry points (what RadixHashJoin()/Filter() call
  *      after staging; bench.py and the parity tests call them directly) ----- */

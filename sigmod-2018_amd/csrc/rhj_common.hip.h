@@ -47,7 +47,7 @@ struct PlanSummary {
     uint64_t tab32_slots;        // total slots of all 32-bit tables
     uint64_t max_lds_slots;      // largest 32-bit table
     uint64_t max_build;          // largest build side
-    uint64_t matches;            // filled by k_offsets / k_fused_total
+    uint64_t matches;            // filled by k_offsets / the fused kernel's last workgroup out
     uint64_t fused_ok;           // every active bucket's build side <= lds_cap (fused path usable)
     uint32_t wide_row_ids;       // two-pass partition: 1 = the intermediate array keeps 16-byte tuples, 0 = 12-byte
     uint32_t row_id_overflow;    // a row id above 2^32 - 1 went through a 12-byte intermediate: run again wide

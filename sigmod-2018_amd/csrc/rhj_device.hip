@@ -76,6 +76,8 @@ struct Ctx {
     int         wide_row_ids = 0;    // 1: never use 12-byte intermediates (env RHJ_WIDE_ROW_IDS)
     int         no_sub = 1;          // 0: take the sub-split path where it applies (env RHJ_SUB=1, rhj_set_subsplit(1)); off by
                                      // default: on 100Mx100M@12 it measures 5.8 ms against 5.3 ms for the fused path (profiles/README.md r02)
+    int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
+    uint32_t    small_tiles = 128;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
     int         sub_lo = 0;          // pass-1 digit bits of the sub-split partition (0 = choose; env RHJ_SUB_LO)
     int         sub_k = -1;          // sub bits (-1 = choose from the relation sizes; env RHJ_SUB_K)
     uint32_t    sub_target = 3100;   // average build tuples per sub-bucket aimed at
@@ -118,6 +120,8 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NO_RESIDENT"))) g.no_resident = atoi(e);
         if ((e = getenv("RHJ_WIDE_ROW_IDS"))) g.wide_row_ids = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
+        if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
+        if ((e = getenv("RHJ_SMALL_TILES"))) { g.small_tiles = (uint32_t)atoi(e); if (g.small_tiles > SM_MAX_TILES) g.small_tiles = SM_MAX_TILES; }
         if ((e = getenv("RHJ_SUB"))) g.no_sub = !atoi(e);
         if ((e = getenv("RHJ_NO_SUB"))) g.no_sub = atoi(e);
         if ((e = getenv("RHJ_SUB_LO"))) g.sub_lo = atoi(e);
@@ -160,6 +164,7 @@ int ctx_init()
         for (const void *k : fused)
             HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     }
+    HIP_TRY(hipFuncSetAttribute((const void *)k_small_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(PT_MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
@@ -444,10 +449,8 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     // the fused path reads 12-byte partitioned tuples when the row ids fit 32 bits; the tiled path reads rhj_tuple
     if (!want_fused) force_wide = true;
     ps.plan = &pa;
-    if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
-
-    HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
-    if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+    ps.hist = (uint64_t *)g.histpsum.p;
+    ps.psum = ps.hist + 2 * bins;
     PlanSummary *hs = (PlanSummary *)g.pin;
     PlanSummary plan;
 
@@ -462,7 +465,100 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     ja.out = nullptr; ja.out_capacity = 0;
     ja.ablate = (uint32_t)g.ablate; ja.pad = 0;
 
-    if (want_fused) {
+    // ---- small joins: two launches for the partition (the plan rides in the second), the fused join third, and
+    // no host memset, no total kernel, no read-back copy (rhj_small.hip.h)
+    bool partitioned = false;      // the small path partitioned and planned, but some bucket needs the tiled path
+    const uint32_t stilesR = (uint32_t)((nR + SM_TILE - 1) / SM_TILE), stilesS = (uint32_t)((nS + SM_TILE - 1) / SM_TILE);
+    if (want_fused && bits <= PT_MAX_BITS && !g.no_small && stilesR <= g.small_tiles && stilesS <= g.small_tiles &&
+        !getenv("RHJ_STAMPS")) {
+        const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;
+        const uint64_t status_words = unit_bound + 1 + 8;                 // 8 ticket words in front
+        RelArgs a0 = ps.r[0], a1 = ps.r[1];
+        a0.tiles = stilesR; a1.tiles = stilesS;
+        if (ensure(g.cntR, (size_t)a0.tiles * 256 * 4) || ensure(g.cntS, (size_t)a1.tiles * 256 * 4) ||
+            ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
+            ensure(g.status, status_words * 8 + 64) ||
+            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
+            return -1;
+        a0.cnt = (uint32_t *)g.cntR.p; a1.cnt = (uint32_t *)g.cntS.p;
+        FusedArgs fa;
+        fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
+        fa.status = (uint64_t *)g.status.p + 8;
+        fa.ticket = (uint32_t *)g.status.p;
+        fa.nR = nR;
+        fa.allow_resident = !g.no_resident; fa.pad = 0;
+        fa.unit_bound = unit_bound;
+        fa.host_summary = (uint64_t *)g.pin;
+        fa.dbg = nullptr;
+        fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p;
+        const uint32_t fused_lds = LDS_BUDGET - FJ_LDS_EXTRA;
+        if (use_ctx_out) {
+            const uint64_t guess = (nR > nS ? nR : nS) + 1024;
+            if (g.out.cap < guess * sizeof(rhj_result_tuple) && ensure(g.out, guess * sizeof(rhj_result_tuple))) return -1;
+            out = (rhj_result_tuple *)g.out.p;
+            out_capacity = g.out.cap / sizeof(rhj_result_tuple);
+        }
+        const uint32_t max_tiles = a0.tiles > a1.tiles ? a0.tiles : a1.tiles;
+        const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
+        bool small_done = false;
+        uint64_t M = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            ja.out = out; ja.out_capacity = out ? out_capacity : 0;
+            fa.j = ja;
+            HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+            RHJ_LAUNCH(k_small_hist, dim3(max_tiles, 2), dim3(SM_BLOCK), 0, g.stream, a0, a1, bits, (uint64_t *)g.status.p, status_words,
+                       (PlanSummary *)g.summary.p);
+            HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+            RHJ_LAUNCH(k_small_scatter, dim3(max_tiles + 1, 2), dim3(SM_BLOCK), small_lds_bytes(bits), g.stream, a0, a1, bits, ps.hist,
+                       ps.psum, pa);
+            HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+            if (nmin / bins <= 7000 && !g.no_resident)
+                RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            else
+                RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            plan = *hs;                                // written by the join kernel's last workgroup (system-scope stores)
+            if (!plan.fused_ok) { partitioned = true; break; }
+            small_done = true;
+            M = plan.matches;
+            if (!use_ctx_out || M <= out_capacity) break;
+            if (ensure(g.out, M * sizeof(rhj_result_tuple))) return -1;    // rare: fan-out above the guess
+            out = (rhj_result_tuple *)g.out.p;
+            out_capacity = M;
+        }
+        if (small_done) {
+            *overflow = false;
+            st.units = plan.units; st.hbm_units = 0; st.max_build = plan.max_build;
+            st.reserved = 3;
+            *matches = M;
+            st.matches = M;
+            if (ctx_out) *ctx_out = out;
+            st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCATTER]);
+            st.ms_scan = 0.f;                          // no scan launch: every scatter workgroup sums the columns it needs
+            st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PROBE]);
+            st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
+            st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+            return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
+        }
+        if (use_ctx_out) { out = nullptr; out_capacity = 0; }
+    }
+
+    if (!partitioned) {
+        if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
+        HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+        if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+    } else {
+        HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+        HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+        HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+        HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+        pa.span_lds = PR_UNIT;                         // plan again with tile-granular units
+        RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+    }
+
+    if (want_fused && !partitioned) {
         // ---- fused LDS path: build + probe + emit in one kernel, chained output offsets.  Launched
         // without waiting for the plan: the grid is the host-side upper bound on the unit count, the
         // LDS allocation the maximum, and the kernel itself returns when the plan found a bucket that
@@ -478,6 +574,8 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
         fa.allow_resident = !g.no_resident; fa.pad = 0;
+        fa.unit_bound = unit_bound;
+        fa.host_summary = nullptr;
         fa.dbg = nullptr;
         fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p;
         if (getenv("RHJ_STAMPS")) {                           // diagnostic runs only
@@ -517,8 +615,6 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
                     RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             }
-            RHJ_LAUNCH(k_fused_total, dim3(1), dim3(1), 0, g.stream, (const uint64_t *)fa.status,
-                               (const PlanSummary *)g.summary.p, unit_bound, &((PlanSummary *)g.summary.p)->matches);
             HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
             HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipGetLastError());
@@ -896,6 +992,7 @@ void rhj_set_force_hbm_table(int on) { g.force_hbm = on; }
 void rhj_set_fused(int on) { g.no_fused = !on; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_subsplit(int on) { g.no_sub = !on; }
+void rhj_set_small(int on) { g.no_small = !on; }
 /* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */
 int rhj_debug_stamps(uint64_t *host, uint64_t units)
 {

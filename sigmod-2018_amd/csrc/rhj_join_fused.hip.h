@@ -40,10 +40,12 @@ struct FusedArgs {
     uint8_t  *stash_cnt;      // [nR + nS] matches per probe tuple, saturating at 255
     uint64_t *stash_row;      // [nR + nS] build row id of the first match
     uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
-    uint32_t *ticket;
+    uint32_t *ticket;         // word 0: next unit; word 1: workgroups that are through (the last one out leaves the match total)
     uint64_t  nR;
     uint32_t  allow_resident;
     uint32_t  pad;
+    uint64_t  unit_bound;     // status words there are
+    uint64_t *host_summary;   // pinned host block that receives the plan summary (with the match total) at the end, or null
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
     uint64_t *ovf;            // [grid][2][FJ_OVF_CAP] build row ids of second and later matches (per workgroup, double-buffered)
     uint32_t *ovf_base;       // [grid][2][FJ_SPAN / 256][16] first overflow slot of (256-tuple group, match ordinal)
@@ -598,8 +600,10 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
 #define FJ_DBG ((uint64_t *)nullptr)
 #define FJ_ABLATE 0u
 #endif
+// The whole body is a device function: k_join_fused runs it over units a host-launched plan wrote, k_small_join
+// (rhj_small.hip.h) as the last phase of its single launch.
 template <bool MAYRES, bool N32>
-__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
+__device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
     __shared__ uint32_t sh_u;
@@ -897,13 +901,37 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
     }
 }
 
-// total matches of the fused path = inclusive prefix of the last unit
-__global__ void k_fused_total(const uint64_t *status, const PlanSummary *summary, uint64_t unit_bound, uint64_t *total_out)
+template <bool MAYRES, bool N32>
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
 {
-    // when the plan rejected the fused path its unit list is the tiled one and can be longer than the
-    // status array: nothing was published, nothing to read
-    const uint64_t n = summary->units;
-    *total_out = (summary->fused_ok && n && n <= unit_bound) ? (status[n - 1] & ((1ull << 62) - 1)) : 0;
+    fj_body<MAYRES, N32>(f, lds_bytes);
+    // The last workgroup out leaves the match total = inclusive prefix of the last unit (every unit publishes one
+    // before it emits; nothing when the plan rejected the fused path: its unit list is the tiled one then).  Both
+    // row-id instantiations of a join are launched and either may run first: the one that returns at once finds the
+    // status words still clear or already complete, and the later launch's total is the one that stays.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this thread's status words are out before it counts itself
+        if (__hip_atomic_fetch_add(f.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(f.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PlanSummary *sum = const_cast<PlanSummary *>(f.j.summary);
+            const uint64_t n = sum->units;
+            uint64_t total = 0;
+            if (sum->fused_ok && n && n <= f.unit_bound) {
+                const unsigned long long v = __hip_atomic_load((unsigned long long *)f.status + (n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 62) == 2) total = v & ((1ull << 62) - 1);
+            }
+            sum->matches = total;
+            if (f.host_summary) {
+                const uint64_t *src = reinterpret_cast<const uint64_t *>(sum);
+                static_assert(sizeof(PlanSummary) % 8 == 0, "summary words");
+                for (uint32_t i = 0; i < sizeof(PlanSummary) / 8; ++i) {
+                    const uint64_t v = i == offsetof(PlanSummary, matches) / 8 ? total : src[i];
+                    __hip_atomic_store(f.host_summary + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace rhj

@@ -41,5 +41,6 @@
 #include "rhj_partition.hip.h"
 #include "rhj_join_tiled.hip.h"
 #include "rhj_join_fused.hip.h"
+#include "rhj_small.hip.h"
 #include "rhj_filter.hip.h"
 #include "rhj_diag.hip.h"
