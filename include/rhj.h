@@ -160,6 +160,10 @@ void rhj_set_subsplit(int on);
  * scan, plan, scatter and the fused join as the phases of ONE kernel launch (csrc/rhj_small.hip.h); 0: the same
  * steps as separate launches.  Results are identical either way (env RHJ_NO_SMALL=1). */
 void rhj_set_small(int on);
+/* How much of a join rhj_get_stats() times with HIP events: 2 (default) every stage, 1 the whole join only, 0 nothing
+ * (all ms_* zero).  Only the small-join path listens: an event between two of its launches costs it ~6 us each (the
+ * next kernel cannot be fed while the previous one drains), 10 % of a 1M x 1M join (env RHJ_TIMING). */
+void rhj_set_timing(int level);
 
 /* ---- device-resident entry points (what RadixHashJoin()/Filter() call
  *      after staging; bench.py and the parity tests call them directly) ----- */

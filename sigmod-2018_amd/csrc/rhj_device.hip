@@ -76,6 +76,7 @@ struct Ctx {
     int         wide_row_ids = 0;    // 1: never use 12-byte intermediates (env RHJ_WIDE_ROW_IDS)
     int         no_sub = 1;          // 0: take the sub-split path where it applies (env RHJ_SUB=1, rhj_set_subsplit(1)); off by
                                      // default: on 100Mx100M@12 it measures 5.8 ms against 5.3 ms for the fused path (profiles/README.md r02)
+    int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 128;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
     int         sub_lo = 0;          // pass-1 digit bits of the sub-split partition (0 = choose; env RHJ_SUB_LO)
@@ -121,6 +122,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_WIDE_ROW_IDS"))) g.wide_row_ids = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
+        if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
         if ((e = getenv("RHJ_SMALL_TILES"))) { g.small_tiles = (uint32_t)atoi(e); if (g.small_tiles > SM_MAX_TILES) g.small_tiles = SM_MAX_TILES; }
         if ((e = getenv("RHJ_SUB"))) g.no_sub = !atoi(e);
         if ((e = getenv("RHJ_NO_SUB"))) g.no_sub = atoi(e);
@@ -502,21 +504,23 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
         bool small_done = false;
         uint64_t M = 0;
+        // An event between two launches costs the join 6 us (the next kernel waits for the previous one to drain and
+        // the event's signal): stage times only when asked for (rhj_set_timing(2))
+        const bool stages = g.timing >= 2;
         for (int attempt = 0; attempt < 2; ++attempt) {
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
-            HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-            RHJ_LAUNCH(k_small_hist, dim3(max_tiles, 2), dim3(SM_BLOCK), 0, g.stream, a0, a1, bits, (uint64_t *)g.status.p, status_words,
-                       (PlanSummary *)g.summary.p);
-            HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+            if (g.timing) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+            RHJ_LAUNCH(k_small_hist, dim3(max_tiles, 2), dim3(SM_BLOCK), 0, g.stream, a0, a1, bits, (uint64_t *)g.status.p, status_words);
+            if (stages) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
             RHJ_LAUNCH(k_small_scatter, dim3(max_tiles + 1, 2), dim3(SM_BLOCK), small_lds_bytes(bits), g.stream, a0, a1, bits, ps.hist,
                        ps.psum, pa);
-            HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+            if (stages) HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
             if (nmin / bins <= 7000 && !g.no_resident)
                 RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             else
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-            HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+            if (g.timing) HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;                                // written by the join kernel's last workgroup (system-scope stores)
@@ -535,11 +539,13 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             *matches = M;
             st.matches = M;
             if (ctx_out) *ctx_out = out;
-            st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCATTER]);
-            st.ms_scan = 0.f;                          // no scan launch: every scatter workgroup sums the columns it needs
-            st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PROBE]);
-            st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
-            st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+            if (stages) {
+                st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCATTER]);
+                st.ms_scan = 0.f;                      // no scan launch: every scatter workgroup sums the columns it needs
+                st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PROBE]);
+                st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
+            }
+            if (g.timing) st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
             return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
         }
         if (use_ctx_out) { out = nullptr; out_capacity = 0; }
@@ -993,6 +999,7 @@ void rhj_set_fused(int on) { g.no_fused = !on; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_subsplit(int on) { g.no_sub = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
+void rhj_set_timing(int level) { g.timing = level < 0 ? 0 : level > 2 ? 2 : level; }
 /* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */
 int rhj_debug_stamps(uint64_t *host, uint64_t units)
 {
@@ -1001,6 +1008,12 @@ int rhj_debug_stamps(uint64_t *host, uint64_t units)
     return hipMemcpy(host, g.dbg.p, units * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #ifdef RHJ_INSTRUMENT
+/* diagnostics build only: per-workgroup start / end stamps of the small path's two partition kernels */
+int rhj_debug_small_stamps(uint64_t *host)
+{
+    RhjApiLock api_lock;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sm_dbg), sizeof(uint64_t) * 4 * 2048) == hipSuccess ? 0 : -1;
+}
 /* diagnostics build only: rate of random 16-byte gathers from per-workgroup regions (tools/gather_bench.py) */
 int rhj_debug_gather_bench(uint32_t region_elems, uint32_t rounds, uint32_t stream_per_round, uint32_t wgs, float *ms)
 {
