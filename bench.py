@@ -400,6 +400,10 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="strong scaling: keep the pair lists sharded (no exchange step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-hbm-table", action="store_true")
+    ap.add_argument("--timing", type=int, default=2, choices=[0, 1, 2],
+                    help="HIP events inside rhj_join_device during the timed steps: 2 = per stage (default; the roofline's kernel "
+                         "times come from them), 1 = whole join, 0 = none.  Below 2 the stage times are collected in a second, "
+                         "untimed pass.  Matters for small joins only: an event between two launches costs them ~6 us")
     args = ap.parse_args()
 
     import torch
@@ -458,6 +462,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rhj.lib.rhj_set_timing(args.timing)
     for _ in range(args.warmup):
         step()
     if rank == 0 or True:
@@ -473,12 +478,23 @@ def main():
             acc[k] += st[k]
     barrier()
     elapsed = time.perf_counter() - t0
+    stage_steps = args.steps
+    if args.timing < 2:                   # stage times from a second pass with the per-stage events switched on
+        rhj.lib.rhj_set_timing(2)
+        stage_steps = min(args.steps, 50)
+        acc = dict.fromkeys(keys, 0.0)
+        for _ in range(stage_steps):
+            step()
+            st = rhj.stats()
+            for k in keys:
+                acc[k] += st[k]
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = rhj.stats()
-    stage = {k: acc[k] / args.steps for k in keys}
+    stage = {k: acc[k] / stage_steps for k in keys}
 
     if rank == 0:
         nR, nS, M = w["nR"], w["nS"], m.value
@@ -508,7 +524,8 @@ def main():
                     "pass1_tile_local": {"ms": stage["ms_hist"], "moved_GBps": gbs(scatter_bytes, stage["ms_hist"])},
                     "pass2_histogram_scan": {"ms": stage["ms_scan"]},
                     "pass2_scatter_runs": {"ms": stage["ms_scatter"], "moved_GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
-        fused = st["path"] == "fused"
+        small = st["path"] == "small"
+        fused = st["path"] in ("fused", "small")
         sub = st["path"] == "subsplit"
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
         probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
@@ -550,7 +567,9 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": w["name"], "id": args.workload, "nR": nR, "nS": nS, "radix_bits": w["bits"],
                        "matches": M, "parallelism": "independent join per GPU" if world > 1 else "1 GPU",
-                       "path": st["path"], "sub_bits": st["sub_bits"], "pass1_bits": st["pass1_bits"],
+                       "path": st["path"], "sub_bits": st["sub_bits"], "pass1_bits": st["pass1_bits"], "timing": args.timing,
+                       "stage_times": ("events of the timed steps" if args.timing == 2 else
+                                       "second pass of %d steps with per-stage events (the timed steps ran with timing %d)" % (stage_steps, args.timing)),
                        "units": st["units"], "max_build_side": st["max_build"]},
             "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -558,7 +577,9 @@ def main():
                          "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"],
                          "formula": "16*nS + 16*nR + 16*matches (SURVEY.md 8d)"},
             "roofline_partition": {"bound": "hbm", "kernel": "radix partition of both relations (all passes: tile-local pass, "
-                                   "pass-2 histogram + scans, run scatter)" if w["bits"] > 8 else "radix partition of both relations (histogram, scans, scatter)",
+                                   "pass-2 histogram + scans, run scatter)" if w["bits"] > 8 else
+                                   "radix partition of both relations (k_small_hist, k_small_scatter: tile histogram, self-scanning scatter)" if small
+                                   else "radix partition of both relations (histogram, scans, scatter)",
                                    "achieved": gbs(part_bytes, part_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": gbs(part_bytes, part_ms) / HBM_PEAK_GBS, "algorithmic_bytes": part_bytes, "ms": part_ms,
                                    "formula": part_formula},

@@ -15,9 +15,9 @@ def set_path(p):
     rhj.lib.rhj_set_fused(0 if p.startswith("tiled") else 1)
     rhj.lib.rhj_set_force_hbm_table(1 if p == "tiled64" else 0)
     rhj.lib.rhj_set_resident(0 if p == "fused_gather" else 1)
-t0 = time.time(); pairs = 0; ran = 0
+t0 = time.time(); pairs = 0; ran = 0; taken = {}
 for it in range(iters):
-    bits = int(rng.choice([1, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
+    bits = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 14, 15]))
     nR = int(rng.choice([1, 17, 300, 4096, 4097, 20000, 65536, 150000, 400000]))
     nS = int(rng.choice([1, 64, 1000, 8191, 50000, 131072, 300000, 600000]))
     kind = int(rng.choice([1, 2, 3, 4]))
@@ -40,7 +40,8 @@ for it in range(iters):
     got = rhj.pairs_to_numpy(t)[:m]
     ok = m == len(want) and (got == want).all()
     pairs += m; ran += 1
+    pth = rhj.stats()["path"]; taken[pth] = taken.get(pth, 0) + 1
     if not ok:
         print("MISMATCH", dict(it=it, seed=seed, bits=bits, nR=nR, nS=nS, kind=kind, dom=dom, path=path, m=m, want=len(want)))
         sys.exit(1)
-print("stress ok: %d of %d joins run (the rest exceed the output bound), %d pairs, %.1f s" % (ran, iters, pairs, time.time() - t0))
+print("stress ok: %d of %d joins run (the rest exceed the output bound), %d pairs, %.1f s; paths taken %s" % (ran, iters, pairs, time.time() - t0, taken))
