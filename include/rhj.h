@@ -143,7 +143,9 @@ void rhj_set_stream(void *hip_stream);
  *   fused (default)  one workgroup per bucket keeps its tag table in LDS, builds, probes and
  *                    emits in one kernel; chosen when every bucket's build side fits LDS;
  *   tiled            tag tables in HBM, tile-granular probe units, count + emit kernels;
- *                    taken automatically when some bucket is too large for LDS, or with
+ *                    taken automatically when some bucket is too large for LDS, when the buckets are tiny
+ *                    (4096 or more of them with fewer than 512 tuples each on average: a fused unit has
+ *                    a fixed cost) unless rhj_set_fused(2) / env RHJ_FORCE_FUSED=1 insists, or with
  *                    rhj_set_fused(0) / env RHJ_NO_FUSED=1;
  *   rhj_set_force_hbm_table(1) additionally builds every table with global atomics
  *                    (64-bit entries), the path of buckets beyond 65534 build tuples. */

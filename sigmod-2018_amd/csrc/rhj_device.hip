@@ -72,6 +72,7 @@ struct Ctx {
     int         force_hbm = 0;
     int         ablate = 0;
     int         no_fused = 0;
+    int         force_fused = 0;     // rhj_set_fused(2): the fused path even where the tiled one is expected to be faster (tiny buckets)
     int         no_resident = 0;
     int         wide_row_ids = 0;    // 1: never use 12-byte intermediates (env RHJ_WIDE_ROW_IDS)
     int         no_sub = 1;          // 0: take the sub-split path where it applies (env RHJ_SUB=1, rhj_set_subsplit(1)); off by
@@ -118,6 +119,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
         if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);
         if ((e = getenv("RHJ_NO_FUSED"))) g.no_fused = atoi(e);
+        if ((e = getenv("RHJ_FORCE_FUSED"))) g.force_fused = atoi(e);
         if ((e = getenv("RHJ_NO_RESIDENT"))) g.no_resident = atoi(e);
         if ((e = getenv("RHJ_WIDE_ROW_IDS"))) g.wide_row_ids = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
@@ -418,7 +420,12 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     }
     // ---- plan arguments (the plan runs behind the partition; a small one-pass partition runs it in its scan launch)
     const uint32_t build_chunk = 4096;
-    const bool want_fused = !g.no_fused && !g.force_hbm;
+    // Thousands of buckets of a few hundred tuples: a fused unit costs ~15 us whatever its size (a dozen barriers and
+    // dependent round trips, one unit per CU at a time), the tiled path's 256-thread probe units run eight to a CU —
+    // 1M x 1M at 15 bits 2.2 ms fused, 0.88 ms tiled; from ~512 tuples per bucket on the fused path is ahead again
+    // (tools/exp_twopass_sizes.py).  rhj_set_fused(2) keeps the fused path regardless.
+    const bool tiny_buckets = bins >= 4096 && (nR > nS ? nR : nS) < (uint64_t)512 * bins;
+    const bool want_fused = !g.no_fused && !g.force_hbm && (g.force_fused || !tiny_buckets);
     const uint32_t lds_max_slots = LDS_BUDGET / 4 / 4 * 4;                 // tiled path: k_build_lds owns the whole LDS
     uint32_t lds_cap = (uint32_t)((uint64_t)lds_max_slots * 4 / 5);        // load factor <= 0.8
     if (want_fused) lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 128) * 2 / 9;   // fused: 4 B entry + >= 0.5 B of slot starts per build tuple
@@ -995,7 +1002,7 @@ int rhj_get_radix_bits(void) { return g.bits; }
 void rhj_set_empty_mode(int null_on_empty) { g.null_on_empty = null_on_empty; }
 void rhj_set_node_pairs(uint64_t pairs) { g.node_pairs = pairs; }
 void rhj_set_force_hbm_table(int on) { g.force_hbm = on; }
-void rhj_set_fused(int on) { g.no_fused = !on; }
+void rhj_set_fused(int on) { g.no_fused = !on; g.force_fused = on >= 2; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_subsplit(int on) { g.no_sub = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }

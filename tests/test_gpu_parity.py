@@ -20,6 +20,7 @@ def rhj():
     r = mod.RHJ(device=0)
     yield r
     set_path(r, "fused")
+    r.lib.rhj_set_fused(1)
     r.lib.rhj_set_empty_mode(0)
 
 
@@ -27,7 +28,7 @@ PATHS = ["fused", "fused_gather", "tiled32", "tiled64"]
 
 
 def set_path(rhj, path):
-    rhj.lib.rhj_set_fused(1 if path.startswith("fused") else 0)
+    rhj.lib.rhj_set_fused(2 if path.startswith("fused") else 0)     # 2: also where the tiny-bucket rule would pick the tiled path
     rhj.lib.rhj_set_resident(0 if path == "fused_gather" else 1)
     rhj.lib.rhj_set_force_hbm_table(1 if path == "tiled64" else 0)
 

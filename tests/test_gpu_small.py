@@ -178,3 +178,24 @@ def test_host_abi_takes_the_small_path(rhj, oracle):
     got = rhj.RadixHashJoin(R, S)
     assert rhj.stats()["path"] == "small"
     same(np.ascontiguousarray(got, dtype=PAIR), oracle.join(R, S, 4), "RadixHashJoin()")
+
+
+def test_tiny_buckets_take_the_tiled_path_unless_told_otherwise(rhj, oracle):
+    """4096+ buckets of a few tuples each: a fused unit per bucket has a fixed cost, the tiled path is chosen
+    (rhj_set_fused(1) = automatic); rhj_set_fused(2) keeps the fused path; results identical."""
+    rng = np.random.default_rng(29)
+    R, S = rel(rng, 120000, 1 << 40), rel(rng, 90000, 1 << 40)
+    S["value"][:60000] = R["value"][rng.integers(0, len(R), size=60000)]
+    rhj.set_bits(13)
+    want = oracle.join(R, S, 13)
+    try:
+        rhj.lib.rhj_set_fused(1)
+        a = dev_join(rhj, R, S)
+        assert rhj.stats()["path"] == "tiled"
+        rhj.lib.rhj_set_fused(2)
+        b = dev_join(rhj, R, S)
+        assert rhj.stats()["path"] == "fused"
+    finally:
+        rhj.lib.rhj_set_fused(1)
+    same(a, want, "tiny buckets, automatic")
+    same(b, want, "tiny buckets, fused kept")

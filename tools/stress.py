@@ -12,7 +12,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.RandomState(seed)
 PATHS = ["fused", "fused_gather", "tiled32", "tiled64"]
 def set_path(p):
-    rhj.lib.rhj_set_fused(0 if p.startswith("tiled") else 1)
+    rhj.lib.rhj_set_fused(0 if p.startswith("tiled") else 2)
     rhj.lib.rhj_set_force_hbm_table(1 if p == "tiled64" else 0)
     rhj.lib.rhj_set_resident(0 if p == "fused_gather" else 1)
 t0 = time.time(); pairs = 0; ran = 0; taken = {}
