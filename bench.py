@@ -40,6 +40,7 @@ WORKLOADS = {
     "c4b12": dict(nR=100_000_000, nS=1_000_000_000, bits=12, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 12 radix bits (experiment)"),
     "c4b13": dict(nR=100_000_000, nS=1_000_000_000, bits=13, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 13 radix bits (experiment)"),
     "c4b15": dict(nR=100_000_000, nS=1_000_000_000, bits=15, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 15 radix bits"),
+    "c3b4": dict(nR=100_000_000, nS=100_000_000, bits=4, dist="uniform", name="100Mx100M uniform u64 FK, 4 radix bits = the reference's N_LSB as shipped (not a BASELINE config: buckets of 6 M tuples, tiled path; with --order any the library's own radix)"),
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
     "c3b13": dict(nR=100_000_000, nS=100_000_000, bits=13, dist="uniform", name="100Mx100M uniform u64 FK, 13 radix bits (experiment)"),
     "c3b15": dict(nR=100_000_000, nS=100_000_000, bits=15, dist="uniform", name="100Mx100M uniform u64 FK, 15 radix bits (experiment)"),
@@ -115,7 +116,7 @@ def make_relations(w, device, seed):
     return R, S
 
 
-def check_properties(R, S, out, m, w):
+def check_properties(R, S, out, m, w, bits=None):
     """size-independent parity properties at full size (FK join, unique R keys)"""
     import torch
     assert m == w["nS"], "FK join must emit one pair per S tuple (got %d)" % m
@@ -125,7 +126,7 @@ def check_properties(R, S, out, m, w):
     assert bool((R[p[:, 0], 0] == S[p[:, 1], 0]).all()), "pair joins unequal keys"
     # every S row id appears exactly once: the wrap-around sum is closed-form
     assert int(out[:, 1].sum()) == (w["nS"] * (w["nS"] - 1) // 2) % (1 << 63), "S row ids are not a permutation"
-    b = S[p[:, 1], 0] & ((1 << w["bits"]) - 1)
+    b = S[p[:, 1], 0] & ((1 << (bits or w["bits"])) - 1)        # (order any: the radix width the library used)
     assert bool((b[1:] >= b[:-1]).all()), "buckets not ascending"
 
 
@@ -400,6 +401,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="strong scaling: keep the pair lists sharded (no exchange step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-hbm-table", action="store_true")
+    ap.add_argument("--order", default="canonical", choices=["canonical", "any"],
+                    help="any: rhj_set_order(1) — same pairs, canonical order of the radix width the library picks from the sizes")
     ap.add_argument("--timing", type=int, default=2, choices=[0, 1, 2],
                     help="HIP events inside rhj_join_device during the timed steps: 2 = per stage (default; the roofline's kernel "
                          "times come from them), 1 = whole join, 0 = none.  Below 2 the stage times are collected in a second, "
@@ -463,10 +466,11 @@ def main():
         torch.cuda.synchronize()
 
     rhj.lib.rhj_set_timing(args.timing)
+    rhj.lib.rhj_set_order(1 if args.order == "any" else 0)
     for _ in range(args.warmup):
         step()
     if rank == 0 or True:
-        check_properties(R, S, out, m.value, w)
+        check_properties(R, S, out, m.value, w, rhj.stats()["radix_bits"])
     keys = ("ms_hist", "ms_scan", "ms_scatter", "ms_plan", "ms_build", "ms_count", "ms_offsets", "ms_probe", "ms_total")
     acc = dict.fromkeys(keys, 0.0)
     barrier()
@@ -568,6 +572,7 @@ def main():
             "config": {"workload": w["name"], "id": args.workload, "nR": nR, "nS": nS, "radix_bits": w["bits"],
                        "matches": M, "parallelism": "independent join per GPU" if world > 1 else "1 GPU",
                        "path": st["path"], "sub_bits": st["sub_bits"], "pass1_bits": st["pass1_bits"], "timing": args.timing,
+                       "order": args.order, "radix_bits_used": st["radix_bits"],
                        "stage_times": ("events of the timed steps" if args.timing == 2 else
                                        "second pass of %d steps with per-stage events (the timed steps ran with timing %d)" % (stage_steps, args.timing)),
                        "units": st["units"], "max_build_side": st["max_build"]},

@@ -162,6 +162,16 @@ void rhj_set_subsplit(int on);
  * scan, plan, scatter and the fused join as the phases of ONE kernel launch (csrc/rhj_small.hip.h); 0: the same
  * steps as separate launches.  Results are identical either way (env RHJ_NO_SMALL=1). */
 void rhj_set_small(int on);
+/* Pair order (env RHJ_ORDER=canonical|any).  0 = canonical (default): the reference's order for the
+ * radix width in force — bucket ascending, probe side = R iff cR >= cS, probe tuples in input order, build matches
+ * in descending position (rhjoin.c:42-57,86,141-250).  1 = any: the same pairs in the canonical order of a radix
+ * width the library picks from the relation sizes (rhj_get_stats().radix_bits says which): for callers whose
+ * answers do not depend on the order — the reference's query executor is one: its view sums are order-free
+ * (inter_res.c:320-339), tests/test_gpu_dropin.py runs it this way — and who therefore need not run big joins on
+ * buckets sized for a CPU cache (100M x 100M: 23.5 ms on 4 bits, 5.2 ms on the library's 13).
+ * rhj_partition_device() always uses the radix width in force. */
+void rhj_set_order(int any);
+int  rhj_get_order(void);
 /* How much of a join rhj_get_stats() times with HIP events: 2 (default) every stage, 1 the whole join only, 0 nothing
  * (all ms_* zero).  Only the small-join path listens: an event between two of its launches costs it ~6 us each (the
  * next kernel cannot be fed while the previous one drains), 10 % of a 1M x 1M join (env RHJ_TIMING). */

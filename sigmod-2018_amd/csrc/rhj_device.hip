@@ -71,6 +71,7 @@ struct Ctx {
     int         null_on_empty = 0;
     int         force_hbm = 0;
     int         ablate = 0;
+    int         order_any = 0;       // 1: pair order not needed, the library picks the radix (env RHJ_ORDER=any, rhj_set_order(1))
     int         no_fused = 0;
     int         force_fused = 0;     // rhj_set_fused(2): the fused path even where the tiled one is expected to be faster (tiny buckets)
     int         no_resident = 0;
@@ -118,6 +119,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
         if ((e = getenv("RHJ_ABLATE"))) g.ablate = atoi(e);
+        if ((e = getenv("RHJ_ORDER"))) g.order_any = (strcmp(e, "any") == 0);
         if ((e = getenv("RHJ_NO_FUSED"))) g.no_fused = atoi(e);
         if ((e = getenv("RHJ_FORCE_FUSED"))) g.force_fused = atoi(e);
         if ((e = getenv("RHJ_NO_RESIDENT"))) g.no_resident = atoi(e);
@@ -883,8 +885,40 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
 // The two-pass partition keeps 12-byte tuples between its passes when the row ids fit 32 bits (decided
 // on the device from a sample).  If a wider row id went through anyway, the pairs carry truncated row
 // ids: the join is run again with 16-byte intermediates.
+// Order mode "any" (rhj_set_order(1), env RHJ_ORDER=any): the caller wants the pairs, not the reference's pair order
+// — the order is a function of N_LSB (bucket-major, side choice per bucket), and a caller who does not depend on it
+// should not pay for a radix chosen for a CPU cache: 100M x 100M takes 23.5 ms on the reference's 4 bits (buckets of
+// 6 M tuples: tables in HBM) and 5.2 ms on 12-13.  The radix is then the library's choice from the relation sizes:
+// build sides of ~16 K tuples per bucket (the fused kernel's best on equal sizes, tools/exp: 12 and 13 bits tie on
+// 100M x 100M), ~6.5 K (build tuples resident in LDS beside their index) when the probe side is four times the build
+// side or more (C4: 14 bits), and for small relations up to 8 bits while an average bucket keeps 512 tuples.  The
+// result is the canonical result OF THAT RADIX: same pairs, deterministic order.
+static int auto_radix_bits(uint64_t nR, uint64_t nS)
+{
+    const uint64_t nmin = nR < nS ? nR : nS, nmax = nR < nS ? nS : nR;
+    const uint64_t target = nmax >= 4 * nmin ? 6500 : 16000;
+    int b = 0;
+    while (b < MAX_BITS && (nmin >> b) > target) ++b;
+    while (b < PT_MAX_BITS && (nmin >> (b + 1)) >= 512) ++b;
+    return b < 1 ? 1 : b;
+}
+
+static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
+                             uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches);
+
 int join_device(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
                 uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
+{
+    if (!g.order_any || nR == 0 || nS == 0) return join_device_radix(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches);
+    const int callers = g.bits;
+    g.bits = auto_radix_bits(nR, nS);
+    const int rc = join_device_radix(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches);
+    g.bits = callers;
+    return rc;
+}
+
+static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
+                             uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
 {
     bool overflow = false;
     SubGeom geo;
@@ -1006,6 +1040,8 @@ void rhj_set_fused(int on) { g.no_fused = !on; g.force_fused = on >= 2; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_subsplit(int on) { g.no_sub = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
+void rhj_set_order(int any) { g.order_any = any != 0; }
+int rhj_get_order(void) { return g.order_any; }
 void rhj_set_timing(int level) { g.timing = level < 0 ? 0 : level > 2 ? 2 : level; }
 /* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */
 int rhj_debug_stamps(uint64_t *host, uint64_t units)
