@@ -777,6 +777,9 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     // ---- phase 2: emit (general form: duplicates and tag collisions walk the index again)
     uint64_t run = sh_base;
     if (!emitting) continue;
+#ifdef FJ_NO_WALK
+    continue;                                         // timing experiment: what the index-walking emit costs the kernel in registers
+#endif
     // FJ_H batches per iteration; a wave's slice of the iteration is contiguous: order (wave, half,
     // round, lane).  FJ_H = 2 (more loads in flight, half the barriers) measured +11 % on the kernel:
     // it spills at the 128-VGPR limit of a 1024-thread workgroup.
