@@ -295,12 +295,33 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *part
         }
     }
     if (__syncthreads_or(has_long)) {
-        // long slots: one at a time, ranked by the whole workgroup (descending value)
+        // Long slots of up to 64 entries (a key with 17..64 duplicates: the contest's relations are full of them — a
+        // bucket of `small` has ~100 such slots): ranked by ONE WAVE each, in registers — lane i holds entry i, its rank
+        // is the number of larger entries (64 scalar broadcasts), and the entry goes to its place; the waves find their
+        // slots in the stripes of the slot array they scan, no barrier.  (Ranked one at a time by the whole workgroup,
+        // with three barriers each, these slots were 190 us of a 300 us unit.)
+        for (uint32_t s0 = w * WAVE; s0 < X.hs; s0 += FJ_BLOCK) {
+            const uint32_t sl = s0 + lane;
+            uint32_t a = 0, n = 0;
+            if (sl < X.hs) { a = X.H(sl + 1u); n = X.H(sl + 2u) - a; }
+            uint64_t todo = __ballot(n > FJ_LONG && n <= (uint32_t)WAVE);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)a, src), sn = (uint32_t)__builtin_amdgcn_readlane((int)n, src);
+                const uint32_t v = lane < sn ? X.ent[sa + lane] : 0u;
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < sn; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j) > v;
+                if (lane < sn) X.ent[sa + r] = v;      // (a wave's LDS operations complete in order: every read above is done)
+            }
+        }
+        __syncthreads();
+        // longer slots: one at a time, ranked by the whole workgroup (descending value)
         for (uint32_t next = 0;;) {
             if (tid == 0) *sh_pick = 0xffffffffu;
             __syncthreads();
             for (uint32_t sl = tid; sl < X.hs; sl += FJ_BLOCK)
-                if (sl >= next && X.H(sl + 2u) - X.H(sl + 1u) > FJ_LONG) { atomicMin(sh_pick, sl); break; }
+                if (sl >= next && X.H(sl + 2u) - X.H(sl + 1u) > (uint32_t)WAVE) { atomicMin(sh_pick, sl); break; }
             __syncthreads();
             const uint32_t pick = *sh_pick;
             if (pick == 0xffffffffu) break;
@@ -430,6 +451,106 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather<
                 }
             }
         }
+    }
+}
+
+// Resident build sides (RES): the matches of a probe key without a round per match.  A slot's entries are sorted by
+// (tag, position) descending, so the entries that carry the key's tag are ONE contiguous run: its start and length
+// come from the 8-entry window's hit mask (slots of up to 8 entries: the foreign-key case) or from two binary
+// searches over the slot (longer slots: duplicate-heavy build sides — the contest's own relations have keys with
+// hundreds of duplicates, where a round per match made a wave spin through its longest chain).  Every entry of the
+// run is verified against the resident tuple's 64-bit key.  cnt = verified matches; first = row id of the first one;
+// run = start | cnt << 16 is what the emit pass needs when cnt >= 2 and the run is CLEAN (every entry a match: the
+// j-th match is entry start + j); fp = some entry of the run belongs to another key (a 16-bit tag collision inside
+// one slot) — with two or more matches beside it the unit takes the index-walking emit.
+__device__ __forceinline__ void fj_run_of(const FjIndex &X, uint64_t key, bool ok, uint32_t &start, uint32_t &len)
+{
+    const uint64_t h = mix64(key);
+    const uint32_t s = X.slot(h);
+    const uint32_t d0 = X.H(s + 1u), n = ok ? X.H(s + 2u) - d0 : 0u;
+    const uint32_t tg = fj_tag(h);
+    if (n <= 8u) {
+        const uint32_t m = fj_window(X, d0, n, tg << 16);
+        start = d0 + (m ? (uint32_t)__builtin_ctz(m) : 0u);
+        len = (uint32_t)__popc(m);
+    } else {
+        uint32_t lo = 0, hi = n;                       // first entry whose tag is <= tg
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((X.ent[d0 + mid] >> 16) > tg) lo = mid + 1u; else hi = mid; }
+        const uint32_t lower = lo;
+        hi = n;                                        // first entry whose tag is < tg
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((X.ent[d0 + mid] >> 16) >= tg) lo = mid + 1u; else hi = mid; }
+        start = d0 + lower;
+        len = lo - lower;
+    }
+}
+
+constexpr uint32_t FJ_RUN_LOCK = 64;             // run entries verified lane by lane before the wave takes a long run together
+__device__ __forceinline__ void fj_count_res(const FjIndex &X, const uint4 *ltup, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
+                                             uint32_t (&c)[FJ_V], uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
+                                             uint32_t (&run)[FJ_V])
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t start[FJ_V], len[FJ_V];
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        fj_run_of(X, ((uint64_t)q[k].y << 32) | q[k].x, okk[k], start[k], len[k]);
+        c[k] = 0; flo[k] = 0; fhi[k] = 0;
+    }
+    // runs of up to FJ_RUN_LOCK entries (the foreign-key case and light duplication): lockstep over the run position,
+    // the four tuples of a lane side by side (LDS reads only)
+    uint32_t longest = 0;
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) longest = max(longest, min(len[k], FJ_RUN_LOCK));
+    for (uint32_t j = 0; __ballot(j < longest) != 0; ++j) {
+        // unconditional loads at a clamped position: the four entry reads, then the four tuple reads, are in flight
+        // together (four predicated read -> read chains one after the other cost 800 cycles per step)
+        uint32_t e[FJ_V];
+        uint4 v[FJ_V];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) e[k] = X.ent[start[k] + (j < len[k] ? j : 0u)];
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) v[k] = ltup[e[k] & 0xffffu];      // (an empty run reads the slot's first entry or a pad entry: position 0)
+#pragma unroll
+        for (int k = 0; k < FJ_V; ++k) {
+            const bool eq = j < min(len[k], FJ_RUN_LOCK) && v[k].x == q[k].x && v[k].y == q[k].y;
+            if (eq && c[k] == 0) { flo[k] = v[k].z; fhi[k] = v[k].w; }
+            c[k] += eq;
+        }
+    }
+    // longer runs (a key with many duplicates on the build side), one tuple at a time by the whole wave: 64 entries per
+    // step instead of one (a lane walking a 600-entry run alone held its wave for 230 us)
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        uint64_t todo = __ballot(len[k] > FJ_RUN_LOCK);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)start[k], src), n = (uint32_t)__builtin_amdgcn_readlane((int)len[k], src);
+            const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane((int)q[k].x, src), ky = (uint32_t)__builtin_amdgcn_readlane((int)q[k].y, src);
+            uint32_t found = (uint32_t)__builtin_amdgcn_readlane((int)c[k], src), f0 = 0, f1 = 0;
+            const bool had = found != 0;
+            for (uint32_t j0 = FJ_RUN_LOCK; j0 < n; j0 += WAVE) {
+                const uint32_t j = j0 + lane;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (j < n) v = ltup[X.ent[s0 + j] & 0xffffu];
+                const uint64_t eqm = __ballot(j < n && v.x == kx && v.y == ky);
+                if (eqm != 0 && found == 0) {
+                    const int fl = __builtin_ctzll(eqm);
+                    f0 = (uint32_t)__builtin_amdgcn_readlane((int)v.z, fl);
+                    f1 = (uint32_t)__builtin_amdgcn_readlane((int)v.w, fl);
+                }
+                found += (uint32_t)__popcll(eqm);
+            }
+            if ((int)lane == src) {
+                c[k] = found;
+                if (!had && found != 0) { flo[k] = f0; fhi[k] = f1; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FJ_V; ++k) {
+        fp[k] = c[k] != len[k];
+        run[k] = start[k] | (c[k] << 16);
     }
 }
 
@@ -585,6 +706,105 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
     }
 }
 
+// Emit pass of a RESIDENT unit some of whose probe tuples have two or more matches, all of them in clean runs
+// (fj_count_res): runs right behind the unit's own phase 1, while its index is still in LDS.  The stash holds, per
+// probe tuple, the count byte and either the first match's row id (count <= 1) or the run (start | count << 16).
+// Groups of 256 tuples are handed out to the waves as in phase 1; inside a 64-tuple round without a multi-match tuple
+// the offsets come from one ballot; otherwise the lanes turn to the round's OUTPUT positions, 64 at a time: position o
+// belongs to the tuple whose inclusive prefix is the first above o (binary search over the lanes by shuffles) and is
+// match o - (its exclusive prefix) of that tuple = entry start + that of its run — any number of matches per tuple at
+// 64 coalesced pairs per store (a lane walking its own 600-match chain wrote one pair per round).
+template <bool N32>
+__device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const FjIndex &X, const uint4 *ltup, uint32_t u, uint64_t base,
+                                            uint32_t *wsum, uint32_t *table, uint32_t *grab)
+{
+    constexpr int V = FJ_V;
+    const JoinArgs &a = f.j;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const Unit un = a.units[u];
+    const uint32_t b = un.bucket;
+    const bool flip = a.histR[b] < a.histS[b];
+    const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
+    const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
+    const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
+    const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    const uint64_t cap = a.out_capacity;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t ngroups = (un.count + 255u) >> 8;
+    {                                                 // group totals (column 0 of the table) -> exclusive starts
+        const uint32_t t = threadIdx.x;
+        uint32_t v = 0;
+        if (t < ngroups) v = __hip_atomic_load(&table[t * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t tot;
+        uint32_t ex = wave_excl_scan_u32(v, &tot);
+        __syncthreads();                              // wsum reuse
+        if (t == 0) *grab = 0;
+        if (lane == 0) wsum[w] = tot;
+        __syncthreads();
+        for (uint32_t i = 0; i < w && i < FJ_GROUPS / WAVE; ++i) ex += wsum[i];
+        if (t < ngroups) __hip_atomic_store(&table[t * 16u], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+    }
+    for (;;) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(grab, 1u);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
+        uint32_t c[V];
+        uint2 first[V], prow[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const uint32_t i = g * 256u + k * WAVE + lane;
+            const bool ok = i < un.count;
+            c[k] = ok ? (scnt[i] & 0x7fu) : 0;
+            first[k] = ok ? srow[i] : make_uint2(0, 0);
+            if (N32) { prow[k] = make_uint2(first[k].y, 0u); first[k].y = 0u; }
+            else     prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
+            if (c[k] >= 2u) c[k] = first[k].x >> 16;  // the exact count sits beside the run's start
+        }
+        uint32_t gstart = 0;
+        if (lane == 0) gstart = __hip_atomic_load(&table[g * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint64_t wat = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)gstart);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (__ballot(c[k] > 1u) == 0) {           // zero or one match per tuple
+                const uint64_t mm = __ballot(c[k] != 0);
+                const uint64_t dst = wat + (uint32_t)__popcll(mm & lt);
+                if (c[k] != 0 && dst < cap) out[dst] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
+                wat += (uint32_t)__popcll(mm);
+            } else {
+                uint32_t t;
+                const uint32_t excl = wave_excl_scan_u32(c[k], &t);
+                const uint32_t incl = excl + c[k];
+                for (uint32_t o0 = 0; o0 < t; o0 += WAVE) {
+                    const uint32_t o = o0 + lane;
+                    uint32_t lo_ = 0;
+#pragma unroll
+                    for (int stp = 32; stp >= 1; stp >>= 1) {
+                        const uint32_t v = __shfl(incl, (int)(lo_ + stp - 1u), 64);
+                        if (v <= o) lo_ += stp;
+                    }
+                    const int src = (int)min(lo_, 63u);
+                    const uint32_t ci = __shfl(c[k], src, 64), ei = __shfl(excl, src, 64);
+                    const uint32_t fx = __shfl(first[k].x, src, 64), fy = __shfl(first[k].y, src, 64);
+                    const uint32_t px = __shfl(prow[k].x, src, 64), py = __shfl(prow[k].y, src, 64);
+                    if (o < t) {
+                        uint32_t bl = fx, bh = fy;
+                        if (ci >= 2u) {
+                            const uint4 v = ltup[X.ent[(fx & 0xffffu) + (o - ei)] & 0xffffu];
+                            bl = v.z; bh = v.w;
+                        }
+                        const uint64_t dst = wat + o;
+                        if (dst < cap) out[dst] = make_pair(flip, px, py, bl, bh);
+                    }
+                }
+                wat += t;
+            }
+        }
+    }
+}
+
 // MAYRES = false compiles the gather path only (the host picks it when the average bucket
 // cannot fit LDS anyway); MAYRES = true decides per unit.
 // A workgroup takes units through the ticket until none is left.  The emit pass of a unit that does
@@ -676,6 +896,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     // ---- phase 1: count (+ stash of the first match when the build tuples are not resident)
     uint32_t mine = 0;
     bool needs_index = false;                         // the emit pass must walk the index again
+    bool has_dup = false;                             // resident unit: some tuple has two or more matches (clean runs: fj_emit_res)
     // The waves take 256-tuple groups from a workgroup counter: with a fixed share per wave the barrier
     // behind this loop waited 20 us of a 156 us unit for the slowest wave's gathers.
     const uint32_t ngroups1 = (un.count + 255u) >> 8;
@@ -696,7 +917,8 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             q[k] = okk[k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
         }
         O.gid = grp;
-        if (RES) fj_count_batch<true, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        uint32_t run[FJ_V];
+        if (RES) fj_count_res(X, ltup, q, okk, c, flo, fhi, fp, run);
         else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
@@ -705,10 +927,13 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
                 // count byte: 0..126 exact, 127 = saturated (recounted in phase 2); bit 7 = some tag hit of
                 // this tuple was a different key, so phase 2 must verify its candidates again
                 scnt[i] = (uint8_t)(min(c[k], 127u) | (fp[k] ? 0x80u : 0u));
-                fj_stash_put<N32>(srow, i, flo[k], fhi[k], q[k].z);
+                // resident units: a tuple with two or more matches keeps its run (start | count << 16) instead of the first row id
+                if (RES && c[k] >= 2u) fj_stash_put<N32>(srow, i, run[k], 0u, q[k].z);
+                else                   fj_stash_put<N32>(srow, i, flo[k], fhi[k], q[k].z);
             }
             mine += c[k];
-            needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
+            if (RES) { needs_index = needs_index || (fp[k] && c[k] >= 2u); has_dup = has_dup || c[k] >= 2u; }
+            else needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
         }
         {                                             // group total for the barrier-free emit pass
             uint32_t gt;
@@ -727,6 +952,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     bool unit_needs_index = __syncthreads_or(needs_index) != 0;   // also publishes wsum
     const uint32_t ovf_total = sh_ovf;
     unit_needs_index = unit_needs_index || ovf_total > FJ_OVF_CAP;
+    const bool unit_res_dup = RES && !unit_needs_index && __syncthreads_or(has_dup) != 0;
     uint64_t total = 0;
 #pragma unroll
     for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
@@ -754,7 +980,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         __syncthreads();
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     }
-    if (emitting && !unit_needs_index) {              // this unit's emit pass needs no index: defer it
+    if (emitting && !unit_needs_index && !unit_res_dup) {   // this unit's emit pass needs no index: defer it
         pend = u;
         pend_total = total;
         pend_dup = ovf_total != 0;
@@ -774,9 +1000,14 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     __syncthreads();
 
     if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (!emitting) continue;
+    if (unit_res_dup) {                               // resident build side, multi-match tuples in clean runs: output-centric emit
+        fj_emit_res<N32>(f, X, ltup, u, sh_base, wsum, O.table, &sh_grab);
+        if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+        continue;
+    }
     // ---- phase 2: emit (general form: duplicates and tag collisions walk the index again)
     uint64_t run = sh_base;
-    if (!emitting) continue;
 #ifdef FJ_NO_WALK
     continue;                                         // timing experiment: what the index-walking emit costs the kernel in registers
 #endif
@@ -798,7 +1029,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
                 q[h][k] = okk[h][k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
                 const uint32_t sb = okk[h][k] ? scnt[i] : 0;
                 c[h][k] = sb & 0x7fu;
-                fpt[h][k] = (sb & 0x80u) != 0;
+                fpt[h][k] = RES || (sb & 0x80u) != 0;      // (a resident unit's stash keeps runs, not first matches, for multi-match tuples)
                 const uint2 fr = okk[h][k] ? srow[i] : make_uint2(0, 0);
                 flo[h][k] = fr.x; fhi[h][k] = N32 ? 0u : fr.y;
             }

@@ -10,8 +10,16 @@ nR, nS = [int(x) for x in sys.argv[1:3]]
 bits = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 w = dict(nR=nR, nS=nS, bits=bits, dist="uniform")
 rhj.set_bits(bits)
-R, S = bench.make_relations(w, rhj.dev, 1234)
-cap = max(nR, nS)
+if len(sys.argv) > 4 and sys.argv[4] == "small":      # the join of `small` with these input sizes (recorded inputs)
+    sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+    import helpers
+    g = helpers.Golden()
+    j = [j for j in g.small["joins"] if len(g.small_join(j["idx"])[0]) == nR and len(g.small_join(j["idx"])[1]) == nS][0]
+    Rh, Sh = g.small_join(j["idx"])
+    R, S = rhj.to_device(Rh), rhj.to_device(Sh)
+else:
+    R, S = bench.make_relations(w, rhj.dev, 1234)
+cap = 20000000 if len(sys.argv) > 4 else max(nR, nS)
 out = torch.empty((cap, 2), dtype=torch.int64, device=rhj.dev)
 m = C.c_uint64(0)
 for i in range(3):
