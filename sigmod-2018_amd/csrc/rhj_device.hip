@@ -520,10 +520,13 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
             if (g.timing) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-            RHJ_LAUNCH(k_small_hist, dim3(max_tiles, 2), dim3(SM_BLOCK), 0, g.stream, a0, a1, bits, (uint64_t *)g.status.p, status_words);
+            // relations of one or two tiles: the scatter workgroups count the digits themselves, two launches in all
+            const int self_hist = max_tiles <= SM_SELF_TILES;
+            if (!self_hist)
+                RHJ_LAUNCH(k_small_hist, dim3(max_tiles, 2), dim3(SM_BLOCK), 0, g.stream, a0, a1, bits, (uint64_t *)g.status.p, status_words);
             if (stages) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
             RHJ_LAUNCH(k_small_scatter, dim3(max_tiles + 1, 2), dim3(SM_BLOCK), small_lds_bytes(bits), g.stream, a0, a1, bits, ps.hist,
-                       ps.psum, pa);
+                       ps.psum, pa, self_hist, (uint64_t *)g.status.p, status_words);
             if (stages) HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
             if (nmin / bins <= 7000 && !g.no_resident)
                 RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
