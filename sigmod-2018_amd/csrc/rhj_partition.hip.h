@@ -380,8 +380,8 @@ __device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint
 }
 
 // cnt[tile2][digit] of pass 2 from the digit bytes pass 1 wrote.  One WAVE per pass-2 tile, no
-// workgroup barrier: the lanes hold the run table, every run is one 64-byte load of the whole wave,
-// sixteen runs' loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
+// workgroup barrier: the lanes hold the run table, four runs share one wave load (sixteen lanes a run, a dword of
+// four digit bytes a lane), eight such loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
 // chain of dependent latencies: 6 us per tile, 0.32 ms for 100M + 100M tuples.)
 constexpr int HR_BLOCK = 256;
 __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits)
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
             uint32_t phys, len;
             pt_run_of(r, tile2, c0 + lane, phys, len);
             const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
+#ifdef HR_BYTE_LOADS      // the first form: one run per wave load, a byte per lane (kept for A/B)
             for (uint32_t q0 = 0; q0 < nrun; q0 += 16) {
                 uint32_t dg[16];
 #pragma unroll
@@ -416,6 +417,35 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
                     }
                 }
             }
+#else
+            // four runs per wave load: sixteen lanes a run, four digit bytes a lane (the digit array is padded by 64 bytes,
+            // a run's last dword may reach past its end: those bytes are not counted); eight loads in flight
+            const uint32_t g4 = lane >> 4, sub4 = (lane & 15u) * 4u;
+            for (uint32_t q0 = 0; q0 < nrun; q0 += 32) {
+                uint32_t dw[8], ll[8], pp[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t run = q0 + (uint32_t)q * 4u + g4;
+                    pp[q] = __shfl(phys, (int)(run & 63u), 64);
+                    const uint32_t l = __shfl(len, (int)(run & 63u), 64);
+                    ll[q] = run < nrun ? l : 0u;
+                    dw[q] = 0;
+                    if (sub4 < ll[q]) dw[q] = *reinterpret_cast<const uint32_t *>(r.dig_in + pp[q] + sub4);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    for (uint32_t off = sub4;;) {
+                        if (off < ll[q]) {
+                            const uint32_t nb = min(ll[q] - off, 4u);
+                            for (uint32_t b = 0; b < nb; ++b) atomicAdd(&h[(dw[q] >> (8u * b)) & 0xffu], 1u);
+                        }
+                        off += WAVE;                          // skewed keys: a run longer than 64 tuples
+                        if (off >= ll[q]) break;
+                        dw[q] = *reinterpret_cast<const uint32_t *>(r.dig_in + pp[q] + off);
+                    }
+                }
+            }
+#endif
         }
         uint32_t *row = r.cnt + (size_t)tile2 * bins;
         for (uint32_t b = lane; b < bins; b += WAVE) row[b] = h[b];
