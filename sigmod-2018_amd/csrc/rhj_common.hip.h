@@ -83,16 +83,58 @@ __device__ __forceinline__ uint64_t lanemask_lt()
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
-__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total)
+// Inclusive scan over the 64 lanes with DPP moves (row shifts inside the 16-lane rows, then the row totals broadcast
+// to the rows behind them): six register-to-register steps of a few cycles each, where the shuffle form went through
+// the LDS crossbar six times in a row (~100 cycles each) — these scans sit in the latency chains of every kernel here.
+// (Lanes a shift has no source for keep the 0 handed in as `old`; row_bcast:15 / :31 write rows 1,3 / 2,3 only.)
+#ifndef RHJ_SHFL_SCAN
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);    // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);    // row_bcast:31
+    return x;
+}
+#else
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 {
     const int lane = threadIdx.x & 63;
-    uint32_t x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t y = __shfl_up(x, d, 64);
         if (lane >= d) x += y;
     }
-    *total = __shfl(x, 63, 64);
+    return x;
+}
+#endif
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t x)
+{
+#ifndef RHJ_SHFL_SCAN
+#define RHJ_DPP64(ctrl, rows)                                                                                   \
+    x += ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rows, 0xf, false) << 32) | \
+         (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rows, 0xf, false)
+    RHJ_DPP64(0x111, 0xf); RHJ_DPP64(0x112, 0xf); RHJ_DPP64(0x114, 0xf); RHJ_DPP64(0x118, 0xf);
+    RHJ_DPP64(0x142, 0xa); RHJ_DPP64(0x143, 0xc);
+#undef RHJ_DPP64
+#else
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+#endif
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total)
+{
+    const uint32_t x = wave_incl_scan_u32(v);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 
@@ -100,23 +142,13 @@ template <int NT>
 __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *total, uint64_t *sm /*NT/64+1*/)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint64_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
+    const uint64_t x = wave_incl_scan_u64(v);
     __syncthreads();                       // sm reuse across calls
     if (lane == 63) sm[w] = x;
     __syncthreads();
     if (threadIdx.x < 64) {                // one wave scans the wave totals
         const uint64_t t = threadIdx.x < NT / 64 ? sm[threadIdx.x] : 0;
-        uint64_t y = t;
-#pragma unroll
-        for (int d = 1; d < NT / 64; d <<= 1) {
-            const uint64_t z = __shfl_up(y, d, 64);
-            if ((int)threadIdx.x >= d) y += z;
-        }
+        const uint64_t y = wave_incl_scan_u64(t);
         if (threadIdx.x < NT / 64) sm[threadIdx.x] = y - t;
         if (threadIdx.x == NT / 64 - 1) sm[NT / 64] = y;
     }

@@ -573,9 +573,9 @@ __device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t
         const uint64_t full = __ballot((v >> 62) == 2);
         const int stop = full ? __ffsll((unsigned long long)full) - 1 : 64;   // nearest inclusive prefix
         uint64_t part = lane <= (uint32_t)stop ? (v & ((1ull << 62) - 1)) : 0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-        excl += part;
+        part = wave_incl_scan_u64(part);              // the sum over the lanes = the scan's last lane
+        excl += ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(part >> 32), 63) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)part, 63);
         if (full) break;
         j -= 64;
     }
