@@ -172,6 +172,8 @@ void rhj_set_small(int on);
  * rhj_partition_device() always uses the radix width in force. */
 void rhj_set_order(int any);
 int  rhj_get_order(void);
+/* the radix width order mode "any" would use for relations of these sizes (pure function: needs no device) */
+int  rhj_auto_radix_bits(uint64_t nR, uint64_t nS);
 /* How much of a join rhj_get_stats() times with HIP events: 2 (default) every stage, 1 the whole join only, 0 nothing
  * (all ms_* zero).  Only the small-join path listens: an event between two of its launches costs it ~6 us each (the
  * next kernel cannot be fed while the previous one drains), 10 % of a 1M x 1M join (env RHJ_TIMING). */
@@ -189,7 +191,7 @@ typedef struct rhj_stats {
     uint64_t n_r, n_s, matches;
     uint64_t units, hbm_units, max_build, table_slots;
     int radix_bits;
-    int reserved;      /* path of the last join: 0 tiled, 1 fused, 2 | k << 8 | lo << 16 sub-split (k sub bits, pass 1 on lo bits) */
+    int reserved;      /* path of the last join: 0 tiled, 1 fused, 2 | k << 8 | lo << 16 sub-split (k sub bits, pass 1 on lo bits), 3 small (fused join behind the two- or three-launch partition of csrc/rhj_small.hip.h) */
 } rhj_stats;
 
 /* Join two device-resident AoS relations (rhj_tuple[nR], rhj_tuple[nS]).

@@ -1044,6 +1044,7 @@ void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_subsplit(int on) { g.no_sub = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
 void rhj_set_order(int any) { g.order_any = any != 0; }
+int rhj_auto_radix_bits(uint64_t nR, uint64_t nS) { return auto_radix_bits(nR, nS); }
 int rhj_get_order(void) { return g.order_any; }
 void rhj_set_timing(int level) { g.timing = level < 0 ? 0 : level > 2 ? 2 : level; }
 /* diagnostic: copy the per-unit phase stamps of the last fused run (RHJ_STAMPS=1) */

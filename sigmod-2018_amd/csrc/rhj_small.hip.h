@@ -1,4 +1,4 @@
-// rhj_small.hip.h — the partition of a small join in two launches
+// rhj_small.hip.h — the partition of a small join in two launches, or in one
 // (part of the device code of librhj.so; rhj_kernels.hip.h includes all of it)
 //
 // 1M x 1M at 8 radix bits moves 48 MB: microseconds at HBM speed.  Such a join is bound by the number of dependent
@@ -10,7 +10,9 @@
 //                    starts and the bucket starts in one go — no scan kernel), then the stable LDS-staged scatter of
 //                    its tile; one extra workgroup leaves hist / psum and runs the plan meanwhile
 // and k_join_fused follows as the third launch; its last workgroup out leaves the match total and the plan summary
-// in pinned host memory, so the host only waits for the stream.
+// in pinned host memory, so the host only waits for the stream.  Relations of one or two tiles (16 K tuples: most
+// joins of the contest's workload) skip k_small_hist: the scatter workgroups count the digits of all the relation's
+// tiles themselves (small_selfhist) and clear the join kernel's words.
 //
 // (A single persistent kernel with grid-wide barriers between these phases was built first and measured slower,
 // 0.30 ms against 0.19 ms: on MI355X a grid barrier costs 6 us bare and 20-50 us with the agent-scope release /

@@ -66,17 +66,7 @@ def test_any_order_is_the_canonical_order_of_the_chosen_radix(rhj, oracle, nR, n
 
 def test_any_order_radix_choice(rhj):
     """100M x 100M would take 13 bits, 100M x 1B 14 (sizes only: nothing is allocated here)."""
-    mod = importlib.import_module("sigmod-2018_amd")
-    # the rule is restated here from include/rhj.h's description; the library's own choice is observed on real joins above
-    def rule(nR, nS):
-        nmin, nmax = min(nR, nS), max(nR, nS)
-        target = 6500 if nmax >= 4 * nmin else 16000
-        b = 0
-        while b < 15 and (nmin >> b) > target:
-            b += 1
-        while b < 8 and (nmin >> (b + 1)) >= 512:
-            b += 1
-        return max(b, 1)
+    rule = rhj.lib.rhj_auto_radix_bits
     assert rule(100_000_000, 100_000_000) == 13 and rule(100_000_000, 1_000_000_000) == 14 and rule(1_000_000, 1_000_000) == 8
     rng = np.random.default_rng(3)
     R = make_rel(rng.integers(0, 1 << 40, size=300_000, dtype=np.uint64))

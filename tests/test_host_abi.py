@@ -87,3 +87,23 @@ def test_scheduler_tokens_and_knobs(lib):
     assert lib.rhj_set_radix_bits(12) == 0 and lib.rhj_get_radix_bits() == 12
     lib.rhj_set_radix_bits(keep)
     assert b"gfx950" in lib.rhj_version()
+
+
+def test_order_mode_and_its_radix_rule(lib):
+    """rhj_set_order / rhj_get_order and the width order mode "any" picks (include/rhj.h): build sides of ~16 K tuples per
+    bucket on comparable sizes, ~6.5 K when the probe side is four times the build side or more, and for small relations
+    up to 8 bits while an average bucket keeps 512 tuples.  Pure host logic: no device is touched."""
+    assert lib.rhj_get_order() == 0
+    lib.rhj_set_order(1)
+    assert lib.rhj_get_order() == 1
+    lib.rhj_set_order(0)
+    assert lib.rhj_get_order() == 0
+    rule = lib.rhj_auto_radix_bits
+    assert rule(100_000_000, 100_000_000) == 13
+    assert rule(100_000_000, 1_000_000_000) == 14 and rule(1_000_000_000, 100_000_000) == 14
+    assert rule(1_000_000, 1_000_000) == 8 and rule(100_000, 100_000) == 7
+    assert rule(1, 1) == 1 and rule(1000, 5) == 1
+    assert rule(1 << 31, 1 << 31) == 15                     # never beyond the widest partition
+    for n in (3, 1000, 77_777, 5_000_000, 300_000_000):
+        for m in (n, 5 * n):
+            assert 1 <= rule(n, m) <= 15 and rule(n, m) == rule(m, n)
