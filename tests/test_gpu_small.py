@@ -199,3 +199,19 @@ def test_tiny_buckets_take_the_tiled_path_unless_told_otherwise(rhj, oracle):
         rhj.lib.rhj_set_fused(1)
     same(a, want, "tiny buckets, automatic")
     same(b, want, "tiny buckets, fused kept")
+
+
+@pytest.mark.parametrize("bits,nR,nS,dom,path", [
+    (4, 200_000, 200_000, 2_000, "small"),        # 100 matches per probe tuple on build sides of 12.5 K: gathered, beyond the overflow stash
+    (9, 4_200_000, 4_200_000, 230_000, "fused"),  # 18 per tuple on gathered build sides through the two-pass partition (12-byte tuples)
+    (2, 20_000, 5_000, 40, "small"),              # resident build sides, runs of 125 entries
+])
+def test_more_matches_than_the_overflow_stash_describes(rhj, oracle, bits, nR, nS, dom, path):
+    """More than 16 matches per probe tuple: on a gathered build side the unit's emit pass walks the index again, on a
+    resident one the run of the key's entries is emitted output-centrically: same pairs, same order as the oracle."""
+    rng = np.random.default_rng(bits * 1000 + dom)
+    R, S = rel(rng, nR, dom), rel(rng, nS, dom)
+    rhj.set_bits(bits)
+    got = dev_join(rhj, R, S)
+    assert rhj.stats()["path"] == path
+    same(got, oracle.join(R, S, bits), "bits=%d" % bits)
