@@ -68,6 +68,11 @@ struct JoinArgs {
     uint64_t         out_capacity;
     uint32_t         ablate;         // timing experiments only (RHJ_ABLATE): 1 no gathers, 2 no table reads
     uint32_t         pad;
+    // tiled path: what the count pass learnt per probe tuple, indexed like the partitioned relations (S behind R): the emit
+    // pass takes tuples with at most one match from here and goes back to the table only for the others
+    uint8_t         *stash_cnt;      // matches, saturating at 255
+    uint64_t        *stash_row;      // build row id of the first match
+    uint64_t         stash_nR;       // S's tuples start here
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)

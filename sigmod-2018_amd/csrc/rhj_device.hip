@@ -475,6 +475,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     ja.unit_flag = (uint32_t *)g.uflag.p;
     ja.out = nullptr; ja.out_capacity = 0;
     ja.ablate = (uint32_t)g.ablate; ja.pad = 0;
+    ja.stash_cnt = nullptr; ja.stash_row = nullptr; ja.stash_nR = nR;
 
     // ---- small joins: two launches for the partition (the plan rides in the second), the fused join third, and
     // no host memset, no total kernel, no read-back copy (rhj_small.hip.h)
@@ -676,8 +677,9 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     st.units = plan.units; st.hbm_units = plan.build_units; st.max_build = plan.max_build;
     st.table_slots = plan.hbm_slots + plan.tab32_slots;
 
-    if (ensure(g.tab32, max_tab32 * 4)) return -1;
+    if (ensure(g.tab32, max_tab32 * 4) || ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8)) return -1;
     ja.tab32 = (uint32_t *)g.tab32.p;
+    ja.stash_cnt = (uint8_t *)g.stash_cnt.p; ja.stash_row = (uint64_t *)g.stash_row.p;
     HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
     if (plan.hbm_slots) {
         if (ensure(g.tab64, plan.hbm_slots * 8)) return -1;

@@ -311,7 +311,8 @@ __device__ __forceinline__ uint4 make_pair(bool flip, uint32_t prl, uint32_t prh
 // 8-slot table chunk per tuple, then the candidates' build tuples.
 template <bool WRITE, class Table>
 __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, const rhj_tuple *pr,
-                                           const rhj_tuple *bd, uint32_t count, bool flip, uint32_t u, uint32_t *wsum)
+                                           const rhj_tuple *bd, uint32_t count, bool flip, uint32_t u, uint32_t *wsum,
+                                           uint8_t *scnt, uint2 *srow)
 {
     constexpr int CH = Table::CH;
     typedef typename Table::slot_t slot_t;
@@ -324,11 +325,18 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
 
     uint4 q[PR_V];
     bool ok[PR_V];
+    // emit pass: a tuple the count pass found at most one match for is served from the stash (count + first match's row id)
+    // and never goes back to the table — on a foreign-key join the emit pass is a stream, not a second probe
+    bool stashed[PR_V];
+    uint32_t sc[PR_V];
+    uint2 sr[PR_V];
 #pragma unroll
     for (int k = 0; k < PR_V; ++k) {
         const uint32_t i = w * (WAVE * PR_V) + k * WAVE + lane;
         ok[k] = i < count;
         q[k] = ok[k] ? pr4[i] : make_uint4(0, 0, 0, 0);
+        stashed[k] = false; sc[k] = 0; sr[k] = make_uint2(0, 0);
+        if (WRITE && ok[k]) { sc[k] = scnt[i]; sr[k] = srow[i]; stashed[k] = sc[k] <= 1u; }
     }
     slot_t s0[PR_V];
     uint32_t tg[PR_V];
@@ -338,7 +346,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
         const uint64_t h = mix64(((uint64_t)q[k].y << 32) | q[k].x);
         s0[k] = T.home(h);
         tg[k] = T.tag(h);
-        if (ok[k] && a.ablate != 2) T.load_chunk(s0[k], e[k]);
+        if (ok[k] && a.ablate != 2 && !stashed[k]) T.load_chunk(s0[k], e[k]);
         else {
 #pragma unroll
             for (int j = 0; j < CH; ++j) e[k][j] = 0;
@@ -364,6 +372,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
         }
         hm[k] = mask; p0[k] = a0; p1[k] = a1;
         more[k] = live;
+        if (WRITE && (stashed[k] || !ok[k])) { hm[k] = 0; more[k] = false; }
     }
 
     // ---- matches per probe tuple
@@ -382,15 +391,16 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
             m[k] = c;
         }
     } else {
-        // first two candidates of every tuple: gather all, then compare
-        uint2 g0[PR_V], g1[PR_V];
+        // first two candidates of every tuple: gather all (the count pass the whole tuple: the first match's row id
+        // goes to the stash), then compare
+        uint4 g0[PR_V], g1[PR_V];
         uint32_t rest[PR_V];
 #pragma unroll
         for (int k = 0; k < PR_V; ++k) {
             uint32_t r = hm[k];
-            g0[k] = make_uint2(0, 0); g1[k] = make_uint2(0, 0);
-            if (r) { r &= r - 1; g0[k] = bd2[2 * (size_t)p0[k]]; }
-            if (r) { r &= r - 1; g1[k] = bd2[2 * (size_t)p1[k]]; }
+            g0[k] = make_uint4(0, 0, 0, 0); g1[k] = make_uint4(0, 0, 0, 0);
+            if (r) { r &= r - 1; if (WRITE) { const uint2 v = bd2[2 * (size_t)p0[k]]; g0[k].x = v.x; g0[k].y = v.y; } else g0[k] = bd4[p0[k]]; }
+            if (r) { r &= r - 1; if (WRITE) { const uint2 v = bd2[2 * (size_t)p1[k]]; g1[k].x = v.x; g1[k].y = v.y; } else g1[k] = bd4[p1[k]]; }
             rest[k] = r;
         }
 #pragma unroll
@@ -399,13 +409,15 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
             const bool eq0 = nc >= 1 && g0[k].x == q[k].x && g0[k].y == q[k].y;
             const bool eq1 = nc >= 2 && g1[k].x == q[k].x && g1[k].y == q[k].y;
             uint32_t c = (uint32_t)eq0 + (uint32_t)eq1;
+            uint2 first = eq0 ? make_uint2(g0[k].z, g0[k].w) : make_uint2(g1[k].z, g1[k].w);      // (meaningful when c != 0)
             fp = fp || (nc >= 1 && !eq0) || (nc >= 2 && !eq1);
             if (rest[k]) {                                // third and later candidates of the chunk
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     if ((rest[k] >> j) & 1u) {
-                        const uint2 v = bd2[2 * (size_t)T.pos(e[k][j])];
+                        const uint4 v = bd4[T.pos(e[k][j])];
                         const bool eq = v.x == q[k].x && v.y == q[k].y;
+                        if (eq && c == 0) first = make_uint2(v.z, v.w);
                         c += eq; fp = fp || !eq;
                     }
                 }
@@ -415,8 +427,9 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
                 entry_t x = T.load(s);
                 while (T.live(x, tg[k])) {
                     if (T.hit(x, tg[k])) {
-                        const uint2 v = bd2[2 * (size_t)T.pos(x)];
+                        const uint4 v = bd4[T.pos(x)];
                         const bool eq = v.x == q[k].x && v.y == q[k].y;
+                        if (eq && c == 0) first = make_uint2(v.z, v.w);
                         c += eq; fp = fp || !eq;
                     }
                     s = T.advance(s, 1);
@@ -424,7 +437,16 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
                 }
             }
             m[k] = c;
+            if (!WRITE) {
+                const uint32_t i = w * (WAVE * PR_V) + k * WAVE + lane;
+                if (ok[k]) { scnt[i] = (uint8_t)min(c, 255u); srow[i] = first; }
+            }
         }
+    }
+    if (WRITE) {
+#pragma unroll
+        for (int k = 0; k < PR_V; ++k)
+            if (stashed[k]) m[k] = sc[k];
     }
 
     // ---- offsets in (wave, round, lane) order
@@ -479,6 +501,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
             if (m[k] == 0) continue;
             uint64_t at = base + off[k];
             const uint32_t prl = q[k].z, prh = q[k].w;
+            if (stashed[k]) { if (at < cap) out[at] = make_pair(flip, prl, prh, sr[k].x, sr[k].y); continue; }
             if (hm[k]) { if (at < cap) out[at] = make_pair(flip, prl, prh, r0[k].x, r0[k].y); ++at; }
             if (rest[k]) {
 #pragma unroll
@@ -511,6 +534,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
             if (m[k] == 0) continue;
             uint64_t at = base + off[k];
             const uint32_t prl = q[k].z, prh = q[k].w;
+            if (stashed[k]) { if (at < cap) out[at] = make_pair(flip, prl, prh, sr[k].x, sr[k].y); continue; }
             slot_t s = s0[k];
             entry_t x = T.load(s);
             while (T.live(x, tg[k])) {
@@ -545,13 +569,16 @@ __global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
     const bool flip = cR < cS;                                         // S is streamed (r_s == 1)
     const rhj_tuple *pr = (flip ? a.partS + a.psumS[b] : a.partR + a.psumR[b]) + un.off;
     const rhj_tuple *bd = flip ? a.partR + a.psumR[b] : a.partS + a.psumS[b];
+    const uint64_t spos = (flip ? a.stash_nR + a.psumS[b] : a.psumR[b]) + un.off;          // the unit's first probe tuple in the stash
+    uint8_t *scnt = a.stash_cnt + spos;
+    uint2 *srow = reinterpret_cast<uint2 *>(a.stash_row + spos);
     const BucketMeta m = a.meta[b];
     if (m.mode == 1) {
         Tab32 T{a.tab32 + m.table_off, m.slots};
-        probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum);
+        probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum, scnt, srow);
     } else {
         Tab64 T{a.tab64 + m.table_off, m.slots};
-        probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum);
+        probe_unit<WRITE>(a, T, pr, bd, un.count, flip, u, wsum, scnt, srow);
     }
 }
 
