@@ -11,6 +11,9 @@ namespace rhj {
 constexpr int PR_BLOCK = 256;                     // probe workgroup
 constexpr int PR_V = 4;                           // probe tuples per thread
 constexpr int PR_UNIT = PR_BLOCK * PR_V;          // 2048 probe tuples per unit
+#ifndef PR_MINW
+#define PR_MINW 5                                 // waves per SIMD the probe kernels are compiled for (96 VGPRs)
+#endif
 
 struct PlanArgs {
     const uint64_t *histR, *histS;
@@ -553,7 +556,7 @@ __device__ __forceinline__ void probe_unit(const JoinArgs &a, const Table &T, co
 }
 
 template <bool WRITE>
-__global__ __launch_bounds__(PR_BLOCK) void k_probe(JoinArgs a)
+__global__ __launch_bounds__(PR_BLOCK, PR_MINW) void k_probe(JoinArgs a)
 {
     __shared__ uint32_t wsum[2 * PR_BLOCK / WAVE];
     // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so
