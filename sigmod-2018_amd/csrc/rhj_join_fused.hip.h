@@ -13,16 +13,20 @@ namespace rhj {
 // order through a ticket, so that a unit's predecessors are always running or done.
 //   build    CSR slot index of the bucket's build side in LDS (fj_build)
 //   phase 1  stream the unit's probe keys; one 8-entry tag window per tuple in LDS; ONE global
-//            gather per candidate (key to verify + row id) — from LDS instead when the build
-//            tuples fit there too (RES, build side <= ~7 K tuples); per probe tuple stash the
-//            match count (u8) and the first match's build row id (u64), further matches go to
-//            the overflow stash (fj_count_batch)
+//            gather per candidate (key to verify + row id); per probe tuple stash the match count
+//            (u8) and the first match's build row id (u64), further matches go to the overflow
+//            stash (fj_count_batch).  When the build tuples fit in LDS too (RES, build side <= ~7 K
+//            tuples) the candidates of a key are taken as ONE run of its sorted slot and verified
+//            there (fj_run_of, fj_count_res): exact counts without a round per match, whatever the
+//            number of duplicates; multi-match tuples stash (run start, count)
 //   chain    publish the unit's match total right away (8-byte {flag,value} word per unit,
 //            agent-scope relaxed atomics)
 //   emit     deferred behind the NEXT unit's build and phase 1: decoupled look-back over the
 //            predecessors (never waits by then), then stream probe row ids + stash + overflow
 //            stash and write the pairs at their final canonical positions (fj_emit_stream).
-//            Units the overflow stash cannot describe emit immediately by walking the index again.
+//            Resident units with multi-match tuples emit right behind their own phase 1, output-
+//            centric from the runs (fj_emit_res); units the stash cannot describe emit immediately by
+//            walking the index again.
 // Random global accesses per probe tuple: one 128-byte line (the gather); everything
 // else is streaming or LDS.
 constexpr int FJ_BLOCK = 1024;
