@@ -175,8 +175,9 @@ int  rhj_get_order(void);
 /* the radix width order mode "any" would use for relations of these sizes (pure function: needs no device) */
 int  rhj_auto_radix_bits(uint64_t nR, uint64_t nS);
 /* How much of a join rhj_get_stats() times with HIP events: 2 (default) every stage, 1 the whole join only, 0 nothing
- * (all ms_* zero).  Only the small-join path listens: an event between two of its launches costs it ~6 us each (the
- * next kernel cannot be fed while the previous one drains), 10 % of a 1M x 1M join (env RHJ_TIMING). */
+ * (all ms_* zero).  An event between two launches keeps the second kernel from being fed while the first drains, ~6 us
+ * each: 10 % of a 1M x 1M join, 1 % of 100M x 100M (env RHJ_TIMING).  A caller that never reads the stage times — the
+ * reference's engine — loses nothing with 0. */
 void rhj_set_timing(int level);
 
 /* ---- device-resident entry points (what RadixHashJoin()/Filter() call

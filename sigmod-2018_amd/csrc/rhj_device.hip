@@ -136,6 +136,11 @@ struct EnvDefaults {
     }
 } env_defaults;
 
+// Stage events by timing level (rhj_set_timing): 2 = all of them, 1 = first and last of a join only, 0 = none.  A record
+// between two kernels keeps the second from being fed while the first drains (~6 us, tools/timeline.sh).
+static inline bool stage_on(int st) { return g.timing >= 2 || (g.timing >= 1 && (st == ST_HIST || st == ST_END)); }
+#define RHJ_STAGE(st) do { if (stage_on(st)) HIP_TRY(hipEventRecord(g.ev[st], g.stream)); } while (0)
+
 int ensure(Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
@@ -218,11 +223,11 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
     if (nrel > 1 && r1.tiles > max_tiles) max_tiles = r1.tiles;
     if (plan && nrel == 2 && max_tiles <= SMALL_TILES) {
         // small join: histogram, {scans + plan} in one single-workgroup launch, scatter — three launches instead of seven
-        HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+        RHJ_STAGE(ST_HIST);
         RHJ_LAUNCH(k_hist_tiles, dim3(max_tiles, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
-        HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+        RHJ_STAGE(ST_SCAN);
         RHJ_LAUNCH(k_small_scan_plan, dim3(1), dim3(1024), 0, g.stream, r0, r1, bits, hist, psum, *plan);
-        HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+        RHJ_STAGE(ST_SCATTER);
         RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
         HIP_TRY(hipGetLastError());
         *plan_done = true;
@@ -233,16 +238,16 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
     if (chunks < 1) chunks = 1;
     if (ensure(g.chunk, (size_t)2 * chunks * bins * 8)) return -1;
     const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
-    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    RHJ_STAGE(ST_SCAN);
     RHJ_LAUNCH(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (uint64_t *)g.chunk.p);
     RHJ_LAUNCH(k_scan_bins, dim3(bins, nrel), dim3(WAVE), 0, g.stream, bits, chunks, (uint64_t *)g.chunk.p, hist);
     RHJ_LAUNCH(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint64_t *)hist, psum);
     RHJ_LAUNCH(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    RHJ_STAGE(ST_SCATTER);
     RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -322,10 +327,10 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     // instantiation not chosen returns at once)
     if (ensure(g.summary, sizeof(PlanSummary))) return -1;
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
-    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
     RHJ_LAUNCH(k_local_part, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    RHJ_STAGE(ST_SCAN);
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
         RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, nrel), dim3(HR_BLOCK), (size_t)bins2 * 4 * (HR_BLOCK / WAVE), g.stream,
@@ -344,7 +349,7 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         RHJ_LAUNCH(k_scan_apply, dim3((bins2 + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, b0, b1, hi, chunks,
                    (const uint64_t *)g.chunk.p, (const uint64_t *)pp);
     }
-    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    RHJ_STAGE(ST_SCATTER);
     uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search
     while (search0 * 2 <= group) search0 *= 2;
     {
@@ -386,6 +391,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
     return ms;
 }
+float stage_ms(int a, int b) { return stage_on(a) && stage_on(b) ? ev_ms(g.ev[a], g.ev[b]) : 0.f; }
 
 // The whole device-side join.  out == nullptr && use_ctx_out: the pairs land in the
 // context's own buffer (grown after the count pass), returned through *ctx_out.
@@ -514,26 +520,23 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
         bool small_done = false;
         uint64_t M = 0;
-        // An event between two launches costs the join 6 us (the next kernel waits for the previous one to drain and
-        // the event's signal): stage times only when asked for (rhj_set_timing(2))
-        const bool stages = g.timing >= 2;
         for (int attempt = 0; attempt < 2; ++attempt) {
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
-            if (g.timing) HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+            RHJ_STAGE(ST_HIST);
             // relations of one or two tiles: the scatter workgroups count the digits themselves, two launches in all
             const int self_hist = max_tiles <= SM_SELF_TILES;
             if (!self_hist)
                 RHJ_LAUNCH(k_small_hist, dim3(max_tiles, 2), dim3(SM_BLOCK), 0, g.stream, a0, a1, bits, (uint64_t *)g.status.p, status_words);
-            if (stages) HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+            RHJ_STAGE(ST_SCATTER);
             RHJ_LAUNCH(k_small_scatter, dim3(max_tiles + 1, 2), dim3(SM_BLOCK), small_lds_bytes(bits), g.stream, a0, a1, bits, ps.hist,
                        ps.psum, pa, self_hist, (uint64_t *)g.status.p, status_words);
-            if (stages) HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+            RHJ_STAGE(ST_PROBE);
             if (nmin / bins <= 7000 && !g.no_resident)
                 RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             else
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-            if (g.timing) HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+            RHJ_STAGE(ST_END);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;                                // written by the join kernel's last workgroup (system-scope stores)
@@ -552,13 +555,11 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             *matches = M;
             st.matches = M;
             if (ctx_out) *ctx_out = out;
-            if (stages) {
-                st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCATTER]);
-                st.ms_scan = 0.f;                      // no scan launch: every scatter workgroup sums the columns it needs
-                st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PROBE]);
-                st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
-            }
-            if (g.timing) st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+            st.ms_hist = stage_ms(ST_HIST, ST_SCATTER);
+            st.ms_scan = 0.f;                          // no scan launch: every scatter workgroup sums the columns it needs
+            st.ms_scatter = stage_ms(ST_SCATTER, ST_PROBE);
+            st.ms_probe = stage_ms(ST_PROBE, ST_END);
+            st.ms_total = stage_ms(ST_HIST, ST_END);
             return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
         }
         if (use_ctx_out) { out = nullptr; out_capacity = 0; }
@@ -566,13 +567,13 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
 
     if (!partitioned) {
         if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
-        HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+        RHJ_STAGE(ST_PLAN);
         if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     } else {
-        HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
-        HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
-        HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
-        HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+        RHJ_STAGE(ST_HIST);
+        RHJ_STAGE(ST_SCAN);
+        RHJ_STAGE(ST_SCATTER);
+        RHJ_STAGE(ST_PLAN);
         pa.span_lds = PR_UNIT;                         // plan again with tile-granular units
         RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
     }
@@ -609,10 +610,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             out = (rhj_result_tuple *)g.out.p;
             out_capacity = g.out.cap / sizeof(rhj_result_tuple);
         }
-        HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
-        HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
-        HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
-        HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+        RHJ_STAGE(ST_PROBE);                          // (no separate build / count / offsets stages on this path)
         bool fused_done = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
@@ -634,7 +632,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
                     RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             }
-            HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+            RHJ_STAGE(ST_END);
             HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
@@ -658,12 +656,12 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             *matches = M;
             st.matches = M;
             if (ctx_out) *ctx_out = out;
-            st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
-            st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
-            st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
-            st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
-            st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
-            st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+            st.ms_hist = stage_ms(ST_HIST, ST_SCAN);
+            st.ms_scan = stage_ms(ST_SCAN, ST_SCATTER);
+            st.ms_scatter = stage_ms(ST_SCATTER, ST_PLAN);
+            st.ms_plan = stage_ms(ST_PLAN, ST_PROBE);
+            st.ms_probe = stage_ms(ST_PROBE, ST_END);
+            st.ms_total = stage_ms(ST_HIST, ST_END);
             return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
         }
         // some bucket needs an HBM table: plan again with tile-granular units
@@ -680,7 +678,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     if (ensure(g.tab32, max_tab32 * 4) || ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8)) return -1;
     ja.tab32 = (uint32_t *)g.tab32.p;
     ja.stash_cnt = (uint8_t *)g.stash_cnt.p; ja.stash_row = (uint64_t *)g.stash_row.p;
-    HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
+    RHJ_STAGE(ST_BUILD);
     if (plan.hbm_slots) {
         if (ensure(g.tab64, plan.hbm_slots * 8)) return -1;
         ja.tab64 = (uint64_t *)g.tab64.p;
@@ -693,10 +691,10 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
                            g.stream, ja, (const uint32_t *)g.ldsb.p);
 
     const unsigned probe_grid = (unsigned)((plan.units + 7) / 8 * 8);
-    HIP_TRY(hipEventRecord(g.ev[ST_COUNT], g.stream));
+    RHJ_STAGE(ST_COUNT);
     if (plan.units)
         RHJ_LAUNCH((k_probe<false>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
-    HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
+    RHJ_STAGE(ST_OFFSETS);
     if (launch_offsets((const uint64_t *)g.ucount.p, (uint64_t *)g.ubase.p,
                        (const uint64_t *)&((PlanSummary *)g.summary.p)->units, 0, plan.units,
                        &((PlanSummary *)g.summary.p)->matches))
@@ -718,23 +716,23 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     } else if (M > out_capacity) {
         rc = 1;
     }
-    HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+    RHJ_STAGE(ST_PROBE);
     if (plan.units && M && out && out_capacity) {
         ja.out = out; ja.out_capacity = out_capacity;
         RHJ_LAUNCH((k_probe<true>), dim3(probe_grid), dim3(PR_BLOCK), 0, g.stream, ja);
     }
-    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    RHJ_STAGE(ST_END);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g.stream));
-    st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
-    st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
-    st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
-    st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
-    st.ms_build = ev_ms(g.ev[ST_BUILD], g.ev[ST_COUNT]);
-    st.ms_count = ev_ms(g.ev[ST_COUNT], g.ev[ST_OFFSETS]);
-    st.ms_offsets = ev_ms(g.ev[ST_OFFSETS], g.ev[ST_PROBE]);
-    st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
-    st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    st.ms_hist = stage_ms(ST_HIST, ST_SCAN);
+    st.ms_scan = stage_ms(ST_SCAN, ST_SCATTER);
+    st.ms_scatter = stage_ms(ST_SCATTER, ST_PLAN);
+    st.ms_plan = stage_ms(ST_PLAN, ST_BUILD);
+    st.ms_build = stage_ms(ST_BUILD, ST_COUNT);
+    st.ms_count = stage_ms(ST_COUNT, ST_OFFSETS);
+    st.ms_offsets = stage_ms(ST_OFFSETS, ST_PROBE);
+    st.ms_probe = stage_ms(ST_PROBE, ST_END);
+    st.ms_total = stage_ms(ST_HIST, ST_END);
     return rc;
 }
 
@@ -833,10 +831,10 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     sa.out = out; sa.out_capacity = out ? out_capacity : 0;
     sa.nR = nR; sa.g = geo; sa.max_bucket = 1u << 20;
 
-    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, p1[0], p1[1], 2, 0, dsum);
     RHJ_LAUNCH(k_local_part, dim3(max1, 2), dim3(PT_BLOCK), scatter_lds_bytes(geo.lo), g.stream, p1[0], p1[1], 0, geo.lo, geo.lo, hi, dsum);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCAN], g.stream));
+    RHJ_STAGE(ST_SCAN);
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);
         RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, 2), dim3(HR_BLOCK), (size_t)D * 4 * (HR_BLOCK / WAVE), g.stream, a[0].r, a[1].r, hi);
@@ -844,7 +842,7 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     RHJ_LAUNCH(k_sub_colsum, dim3(bins1 << geo.kb, 2), dim3(256), 0, g.stream, a[0], a[1], geo);
     RHJ_LAUNCH(k_sub_segscan, dim3(2), dim3(1024), 0, g.stream, a[0], a[1], geo);
     RHJ_LAUNCH(k_sub_apply, dim3(bins1 << geo.kb, 2), dim3(256), 0, g.stream, a[0], a[1], geo);
-    HIP_TRY(hipEventRecord(g.ev[ST_SCATTER], g.stream));
+    RHJ_STAGE(ST_SCATTER);
     uint32_t search0 = 1;
     while (search0 * 2 <= group) search0 *= 2;
     {
@@ -855,15 +853,15 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
         const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;
         RHJ_LAUNCH(k_scatter_sub, dim3(want, 2), dim3(SS_BLOCK), SS_LDS_BYTES, g.stream, a[0], a[1], geo, search0, (const PlanSummary *)dsum);
     }
-    HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+    RHJ_STAGE(ST_PLAN);
     RHJ_LAUNCH(k_sub_plan, dim3((nsub + 255) / 256), dim3(256), 0, g.stream, sa);
-    HIP_TRY(hipEventRecord(g.ev[ST_BUILD], g.stream));
+    RHJ_STAGE(ST_BUILD);
     RHJ_LAUNCH(k_sub_join, dim3((unsigned)(nsub + extra_cap)), dim3(SJ_BLOCK), SJ_LDS_BYTES, g.stream, sa, nsub);
-    HIP_TRY(hipEventRecord(g.ev[ST_OFFSETS], g.stream));
+    RHJ_STAGE(ST_OFFSETS);
     RHJ_LAUNCH(k_sub_bscan, dim3(1), dim3(1024), 0, g.stream, sa);
-    HIP_TRY(hipEventRecord(g.ev[ST_PROBE], g.stream));
+    RHJ_STAGE(ST_PROBE);
     if (out) RHJ_LAUNCH(k_sub_emit, dim3(bins), dim3(SE_BLOCK), 0, g.stream, sa);
-    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    RHJ_STAGE(ST_END);
     struct Back { PlanSummary p; SjSummary s; } *hb = (Back *)g.pin;
     HIP_TRY(hipMemcpyAsync(hb, g.summary.p, sizeof(Back), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipGetLastError());
@@ -876,14 +874,14 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     st.units = nsub + hb->s.extra; st.hbm_units = 0; st.max_build = hb->s.max_build;
     st.reserved = 2 | (geo.kb << 8) | (geo.lo << 16);
     if (ctx_out) *ctx_out = out;
-    st.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
-    st.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
-    st.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
-    st.ms_plan = ev_ms(g.ev[ST_PLAN], g.ev[ST_BUILD]);
-    st.ms_build = ev_ms(g.ev[ST_BUILD], g.ev[ST_OFFSETS]);
-    st.ms_offsets = ev_ms(g.ev[ST_OFFSETS], g.ev[ST_PROBE]);
-    st.ms_probe = ev_ms(g.ev[ST_PROBE], g.ev[ST_END]);
-    st.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    st.ms_hist = stage_ms(ST_HIST, ST_SCAN);
+    st.ms_scan = stage_ms(ST_SCAN, ST_SCATTER);
+    st.ms_scatter = stage_ms(ST_SCATTER, ST_PLAN);
+    st.ms_plan = stage_ms(ST_PLAN, ST_BUILD);
+    st.ms_build = stage_ms(ST_BUILD, ST_OFFSETS);
+    st.ms_offsets = stage_ms(ST_OFFSETS, ST_PROBE);
+    st.ms_probe = stage_ms(ST_PROBE, ST_END);
+    st.ms_total = stage_ms(ST_HIST, ST_END);
     return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
 }
 
@@ -975,20 +973,20 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
         if (ctx_out) *ctx_out = d_out;
     }
     uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
-    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
                        (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
     if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
     RHJ_LAUNCH(k_filter_write, dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
                        (const uint64_t *)g.fbase.p, d_out);
-    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    RHJ_STAGE(ST_END);
     HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g.stream));
     *hits = *(uint64_t *)g.pin;
     memset(&g.stats, 0, sizeof(g.stats));
     g.stats.n_r = n; g.stats.matches = *hits;
-    g.stats.ms_total = g.stats.ms_probe = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    g.stats.ms_total = g.stats.ms_probe = stage_ms(ST_HIST, ST_END);
     return 0;
 }
 
@@ -1003,20 +1001,20 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
         ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary)))
         return -1;
     uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
-    HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+    RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_filter_mask_eq2, dim3((unsigned)tiles), dim3(256), 0, g.stream, colA, selA, colB, selB, n,
                (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
     if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
     RHJ_LAUNCH(k_filter_write, dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
                        (const uint64_t *)g.fbase.p, d_out);
-    HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+    RHJ_STAGE(ST_END);
     HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g.stream));
     *hits = *(uint64_t *)g.pin;
     memset(&g.stats, 0, sizeof(g.stats));
     g.stats.n_r = n; g.stats.matches = *hits;
-    g.stats.ms_total = g.stats.ms_probe = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    g.stats.ms_total = g.stats.ms_probe = stage_ms(ST_HIST, ST_END);
     return 0;
 }
 
@@ -1074,13 +1072,13 @@ int rhj_debug_gather_bench(uint32_t region_elems, uint32_t rounds, uint32_t stre
     HIP_TRY(hipMemsetAsync(reg, 1, reg_bytes, g.stream));
     HIP_TRY(hipMemsetAsync(str, 2, str_bytes, g.stream));
     for (int rep = 0; rep < 3; ++rep) {
-        HIP_TRY(hipEventRecord(g.ev[ST_HIST], g.stream));
+        RHJ_STAGE(ST_HIST);
         RHJ_LAUNCH(k_gather_bench, dim3(wgs), dim3(FJ_BLOCK), 0, g.stream, (const rhj_tuple *)reg, region_elems, rounds,
                    (const uint4 *)str, stream_per_round, (uint4 *)sink);
-        HIP_TRY(hipEventRecord(g.ev[ST_END], g.stream));
+        RHJ_STAGE(ST_END);
         HIP_TRY(hipStreamSynchronize(g.stream));
     }
-    *ms = ev_ms(g.ev[ST_HIST], g.ev[ST_END]);
+    *ms = stage_ms(ST_HIST, ST_END);
     (void)hipFree(reg); (void)hipFree(str); (void)hipFree(sink);
     return 0;
 }
@@ -1134,7 +1132,7 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
     if (!hh) return -1;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (run_partition(ps, bits, 1, attempt == 1 || g.wide_row_ids != 0, false)) { free(hh); return -1; }
-        HIP_TRY(hipEventRecord(g.ev[ST_PLAN], g.stream));
+        RHJ_STAGE(ST_PLAN);
         PlanSummary *hs = (PlanSummary *)g.pin;
         HIP_TRY(hipMemcpyAsync(hh, ps.hist, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipMemcpyAsync(hh + bins, ps.psum, (size_t)bins * 8, hipMemcpyDeviceToHost, g.stream));
@@ -1149,10 +1147,10 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
     free(hh);
     memset(&g.stats, 0, sizeof(g.stats));
     g.stats.n_r = n; g.stats.radix_bits = bits;
-    g.stats.ms_hist = ev_ms(g.ev[ST_HIST], g.ev[ST_SCAN]);
-    g.stats.ms_scan = ev_ms(g.ev[ST_SCAN], g.ev[ST_SCATTER]);
-    g.stats.ms_scatter = ev_ms(g.ev[ST_SCATTER], g.ev[ST_PLAN]);
-    g.stats.ms_total = ev_ms(g.ev[ST_HIST], g.ev[ST_PLAN]);
+    g.stats.ms_hist = stage_ms(ST_HIST, ST_SCAN);
+    g.stats.ms_scan = stage_ms(ST_SCAN, ST_SCATTER);
+    g.stats.ms_scatter = stage_ms(ST_SCATTER, ST_PLAN);
+    g.stats.ms_total = stage_ms(ST_HIST, ST_PLAN);
     return 0;
 }
 
