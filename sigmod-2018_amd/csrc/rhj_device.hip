@@ -144,9 +144,15 @@ static inline bool stage_on(int st) { return g.timing >= 2 || (g.timing >= 1 && 
 int ensure(Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
+    static const bool trace = getenv("RHJ_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "rhj-trace:   workspace buffer grows %zu -> %zu bytes (hipFree + hipMalloc)\n", b.cap, bytes);
+    const size_t was = b.cap;
     if (b.p) HIP_TRY(hipFree(b.p));
     b.p = nullptr; b.cap = 0;
+    // first allocation: what is asked for and an eighth; after that at least double — a query plan's joins come in every
+    // size and each regrowth is a hipFree + hipMalloc (two device-wide synchronisations): 41 of them in the `small` run
     size_t want = bytes + bytes / 8 + 4096;
+    if (was && want < 2 * was) want = 2 * was;
     HIP_TRY(hipMalloc(&b.p, want));
     b.cap = want;
     return 0;
@@ -1481,17 +1487,22 @@ void *rhj_dev_alloc(size_t bytes)
 {
     RhjApiLock api_lock;
     if (ctx_init()) return nullptr;
-    size_t want = bytes < 256 ? 256 : bytes;
-    if (want <= ((size_t)1 << 20)) { size_t c = 256; while (c < want) c <<= 1; want = c; }      // power-of-two classes
-    else want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);                       // 1 MiB granules
+    // size classes 2^k and 1.5 * 2^k (a query plan asks for a few dozen different sizes; with 1 MiB granules every one of them
+    // was a hipMalloc — a device-wide synchronisation of 50-150 us — the first time: 79 during the `small` run), and a cached
+    // block of up to twice the class is taken before the driver is asked
+    size_t want = 256;
+    const size_t need = bytes < 256 ? 256 : bytes;
+    while (want < need) { const size_t mid = want + want / 2; if (want >= ((size_t)1 << 20) && mid >= need) { want = mid; break; } want <<= 1; }
     auto it = g.free_blocks.lower_bound(want);
-    if (it != g.free_blocks.end() && it->first <= want + want / 4) {
+    if (it != g.free_blocks.end() && it->first <= 2 * want) {
         void *p = it->second;
         g.live_blocks[p] = it->first;
         g.free_blocks.erase(it);
         return p;
     }
     void *p = nullptr;
+    static const bool trace = getenv("RHJ_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "rhj-trace:   hipMalloc %zu bytes (no cached block of that size)\n", want);
     if (hipMalloc(&p, want) != hipSuccess) {
         // out of device memory: give the cached blocks back and try once more
         (void)hipStreamSynchronize(g.stream);
@@ -1515,6 +1526,21 @@ void rhj_dev_free(void *p)
     g.live_blocks.erase(it);
 }
 void *rhj_dev_stream(void) { return ctx_init() ? nullptr : (void *)g.stream; }
+// Workspace of joins over relations of up to `rows` tuples a side, allocated now (InitRelationMap knows the base relations'
+// sizes: the first joins of a plan then find their buffers in place instead of growing them one by one).
+int rhj_dev_reserve(uint64_t rows)
+{
+    RhjApiLock api_lock;
+    if (ctx_init() || rows == 0 || rows >= (1ull << 32)) return -1;
+    const uint64_t tiles = (rows + SM_TILE - 1) / SM_TILE + 1, units = 256 + 2 * rows / FJ_BATCH + 16;
+    if (ensure(g.partR, rows * sizeof(rhj_tuple)) || ensure(g.partS, rows * sizeof(rhj_tuple)) ||
+        ensure(g.cntR, (size_t)tiles * 256 * 4) || ensure(g.cntS, (size_t)tiles * 256 * 4) ||
+        ensure(g.stash_cnt, 2 * rows + 64) || ensure(g.stash_row, (2 * rows + 8) * 8) ||
+        ensure(g.status, (units + 9) * 8 + 64) || ensure(g.units, units * sizeof(Unit)) ||
+        ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
+        return -1;
+    return 0;
+}
 // Device copy of a host column for the resident operators: the registered copy, or — for a column nobody
 // registered — a fresh block uploaded now, returned in *temp for the caller to rhj_dev_free() once the
 // kernels that read it are queued (blocks are reused in stream order).

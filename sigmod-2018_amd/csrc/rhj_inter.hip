@@ -319,17 +319,28 @@ int rhj_sum_gather_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t
 rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS)
 {
     RhjApiLock api_lock;
-    rhj_result_tuple *out = nullptr;
     uint64_t m = 0;
     TRACE("RadixHashJoin %lu x %lu", (unsigned long)relR->num_tuples, (unsigned long)relS->num_tuples);
-    if (rhj_dev_join(relR->tuples, relR->num_tuples, relS->tuples, relS->num_tuples, &out, &m) < 0) die("RadixHashJoin");
+    // The pairs go straight into the block the result list will own (no copy out of the join's workspace): sized for one
+    // pair per tuple of the larger side; a join with more matches than that says so (rc 1, exact count) and runs once
+    // more into a block of the right size — 4 of the 88 joins of `small`.
+    uint64_t cap = (relR->num_tuples > relS->num_tuples ? relR->num_tuples : relS->num_tuples) + 1024;
+    void *d = rhj_dev_alloc(cap * sizeof(rhj_result_tuple));
+    if (!d) die("RadixHashJoin");
+    int rc = rhj_join_device(relR->tuples, relR->num_tuples, relS->tuples, relS->num_tuples, (rhj_result_tuple *)d, cap, &m);
+    if (rc == 1) {
+        rhj_dev_free(d);
+        cap = m;
+        d = rhj_dev_alloc(cap * sizeof(rhj_result_tuple));
+        if (!d) die("RadixHashJoin");
+        rc = rhj_join_device(relR->tuples, relR->num_tuples, relS->tuples, relS->num_tuples, (rhj_result_tuple *)d, cap, &m);
+    }
+    if (rc != 0) die("RadixHashJoin");
     if (m == 0) {
+        rhj_dev_free(d);
         if (rhj_host_null_on_empty()) return nullptr;          // THREADS 1 behaviour
         return make_result(rhj_dev_alloc(8), 0);               // as shipped: an empty head (rhjoin.c:356-359)
     }
-    void *d = rhj_dev_alloc(m * sizeof(rhj_result_tuple));      // the join's own buffer is reused by the next join
-    if (!d) die("RadixHashJoin");
-    check(hipMemcpyAsync(d, out, m * sizeof(rhj_result_tuple), hipMemcpyDeviceToDevice, stream()), "copying the match list");
     return make_result(d, m);
 }
 
@@ -790,6 +801,9 @@ int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)     
         i++;
         TRACE("InitRelationMap: relation %d loaded", i - 1);
     }
+    uint64_t most = 0;
+    for (int k = 0; k < i; ++k) most = rel_map[k].num_tuples > most ? rel_map[k].num_tuples : most;
+    if (most) (void)rhj_dev_reserve(most);              // the joins' workspace for inputs of the base relations' size
     return 0;
 }
 

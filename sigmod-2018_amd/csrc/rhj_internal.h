@@ -23,6 +23,7 @@ void *rhj_dev_stream(void);                        /* hipStream_t */
 /* device copy of a host column: the REGISTERED copy (*temp = NULL), or a block uploaded for this call that the
  * caller hands back with rhj_dev_free(*temp) once the kernels reading it are queued */
 const uint64_t *rhj_dev_column(const uint64_t *host_col, uint64_t rows, void **temp);
+int   rhj_dev_reserve(uint64_t rows);
 int   rhj_dev_register_column(const uint64_t *host_col, uint64_t rows, const void *pin_base, uint64_t pin_bytes);
 void  rhj_dev_unregister_column(const uint64_t *host_col);
 int   rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, rhj_result_tuple **out,

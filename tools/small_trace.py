@@ -27,3 +27,7 @@ for (t0, l0), (t1, _) in zip(ts, ts[1:]):
     a = ops.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += t1 - t0
 for name, (n, tot) in sorted(ops.items(), key=lambda kv: -kv[1][1]):
     print("  %-34s %4d calls  %7.2f ms in all  %6.3f ms each (until the next operator starts)" % (name, n, tot, tot / n))
+misses = [l for l in r.stderr.decode().splitlines() if "hipMalloc" in l and "grows" not in l]
+grows = [l for l in r.stderr.decode().splitlines() if "workspace buffer grows" in l]
+print("workspace buffers grown (hipFree + hipMalloc each): %d" % len(grows))
+print("device allocations that went to hipMalloc during the run: %d" % len(misses))
