@@ -200,11 +200,45 @@ def cpu_baseline(w):
     return head
 
 
+class _Engine:
+    """One engine process kept alive: relation names + Done once, then batches of queries ended by F — the protocol of the
+    reference's own driver (handler.c:66-97 loops over batches until EOF; submission/harness.cpp:206-299 streams them)."""
+
+    def __init__(self, path, cwd, env, head):
+        import subprocess, tempfile
+        self.err = tempfile.TemporaryFile()
+        self.t_start = time.perf_counter()
+        self.p = subprocess.Popen([path], cwd=cwd, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=self.err, bufsize=0)
+        self.p.stdin.write(head.encode())
+
+    def batch(self, queries):
+        """Submits one batch and returns its answer lines (the engine flushes stdout before it reads on, handler.c:68)."""
+        self.p.stdin.write(("\n".join(queries) + "\nF\n").encode())
+        out = []
+        for _ in queries:
+            line = self.p.stdout.readline()
+            if not line:
+                self.err.seek(0)
+                raise RuntimeError("engine ended early: " + self.err.read().decode()[-1000:])
+            out.append(line.decode().rstrip("\n"))
+        return out
+
+    def close(self):
+        self.p.stdin.close()
+        rc = self.p.wait(timeout=120)
+        if rc != 0:
+            self.err.seek(0)
+            raise RuntimeError("engine exit code %d: %s" % (rc, self.err.read().decode()[-1000:]))
+
+
 def run_small(args, world, rank, local, dist):
-    """One engine process per rank and step (oracle/_ref/radixhash_rhj_resident: handler.c, query.c, stats.c,
-    best_tree.c, relation_list.c of the reference + librhj.so) on the rank's share of the queries; rank 0
-    merges the answers in query order and checks them against small.result (tests/golden)."""
-    import subprocess, tempfile
+    """BASELINE configs[4] in its query-sharded form.  ONE engine process per rank stays alive for the whole run
+    (oracle/_ref/radixhash_rhj_resident: handler.c, query.c, stats.c, best_tree.c, relation_list.c of the reference +
+    librhj.so): it loads the relations once, a step is one BATCH of the rank's share of the 50 queries, and the timed
+    region is batch submission -> last answer line — HIP start-up and the column upload are reported beside it, not in
+    `value` (a process per step measured 0.3 s of start-up around 25 ms of query work).  Rank 0 merges the answers in
+    query order and checks them against small.result (tests/golden)."""
+    import tempfile
     import numpy as np
     for p in (os.path.join(HERE, "tests"), os.path.join(HERE, "oracle")):
         if p not in sys.path:
@@ -225,35 +259,34 @@ def run_small(args, world, rank, local, dist):
         names.append("r%d" % i)
     queries = [l for l in g.small["work_lines"] if "|" in l]
     mine = [i for i in range(len(queries)) if i % world == rank]
+    my_queries = [queries[i] for i in mine]
     head = "\n".join(names) + "\nDone\n"
-    stdin = (head + "\n".join(queries[i] for i in mine) + "\nF\n").encode()
     env = dict(os.environ, RHJ_DEVICE=str(local))
-
-    def run(path, data):
-        r = subprocess.run([path], input=data, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        if r.returncode != 0:
-            raise RuntimeError(r.stderr.decode()[-1000:])
-        return r.stdout.decode().splitlines()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        run(exe, stdin)
+    eng = _Engine(exe, tmp, env, head)
+    lines = eng.batch(my_queries) if my_queries else []        # first batch: start-up, load, first-touch of every workspace
+    startup = time.perf_counter() - eng.t_start
+    for _ in range(max(args.warmup - 1, 0)):
+        eng.batch(my_queries)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lines = run(exe, stdin)
+        if my_queries:
+            lines = eng.batch(my_queries)
     barrier()
     elapsed = time.perf_counter() - t0
+    eng.close()
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed, startup], dtype=torch.float64)
         if dist.get_backend() == "nccl":
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, startup = float(t[0].item()), float(t[1].item())
         gathered = [None] * world
         dist.all_gather_object(gathered, (mine, lines))
     else:
@@ -265,22 +298,31 @@ def run_small(args, world, rank, local, dist):
             for i, l in zip(idx, ls):
                 answers[i] = l
         assert answers == g.small["result_lines"], "the merged answers differ from small.result"
-        res = {"metric": "queries/s on the SIGMOD'18 small workload (whole engine processes, start-up included)",
+        res = {"metric": "queries/s on the SIGMOD'18 small workload (persistent engine per rank; batch submission -> last answer)",
                "value": len(queries) * args.steps / elapsed, "unit": "queries/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "SIGMOD'18 small (fixture)",
                "config": {"workload": WORKLOADS["small"]["name"], "id": "small", "queries": len(queries),
-                          "parallelism": "queries round-robin over %d rank(s), no collective on the data path" % world,
+                          "parallelism": "the 50 queries of a batch dealt round-robin over %d rank(s) (a query's joins are a dependent "
+                                         "chain, query.c:408-461: the query is the unit that shards); one persistent engine per rank; "
+                                         "no collective on the data path" % world,
+                          "startup_s": startup,
+                          "startup_note": "process start + HIP runtime initialisation + relation load/upload + the first batch; not in `value`",
                           "answers": "identical to small.result"},
                "roofline": None}
         if world == 1 and not args.no_cpu_baseline and os.path.exists(ref):
-            all_stdin = (head + "\n".join(queries) + "\nF\n").encode()
+            cpu = _Engine(ref, tmp, dict(os.environ), head)
+            ref_lines = cpu.batch(queries)                    # warm-up batch (page cache, allocator)
+            n_ref = 3
             t1 = time.perf_counter()
-            ref_lines = run(ref, all_stdin)
-            dt = time.perf_counter() - t1
+            for _ in range(n_ref):
+                ref_lines = cpu.batch(queries)
+            dt = (time.perf_counter() - t1) / n_ref
+            cpu.close()
             res["cpu_baseline"] = {"value": len(queries) / dt, "unit": "queries/s", "cores": 4, "kind": "reference",
-                                   "sample": "the reference engine as shipped (THREADS 4), all 50 queries, %.3f s; answers %s" % (
-                                       dt, "identical" if ref_lines == g.small["result_lines"] else "DIFFER")}
+                                   "sample": "the reference engine as shipped (THREADS 4), kept alive the same way: batches of all 50 queries, "
+                                             "%.3f s per batch (mean of %d after one warm-up batch); answers %s" % (
+                                                 dt, n_ref, "identical" if ref_lines == g.small["result_lines"] else "DIFFER")}
         print(json.dumps(res))
 
 
@@ -335,9 +377,11 @@ def run_smalljoins(args, rhj, world, rank, backend, dist):
 
 def run_strong(args, w, rhj, world, rank, backend, dist):
     """ONE join of the workload sharded over the ranks by bucket range: the relations are replicated
-    (same seed on every rank: a device-resident column store per GPU), every rank histograms both, selects the tuples
-    of its bucket range, joins them with rhj_join_device, and the pair lists are exchanged with the exact-size
-    all-gather-v so that every rank ends with the canonical result.  Total work is fixed: "scaling": "strong"."""
+    (same seed on every rank: a device-resident column store per GPU), every rank takes a contiguous bucket range of
+    equal width and joins it with ONE call — rhj_join_device_range: the join's first partition pass drops the other
+    ranks' buckets while it reads the relations, nothing runs in front of the join — and the pair lists are exchanged
+    with the exact-size all-gather-v so that every rank ends with the canonical result.  Total work is fixed:
+    "scaling": "strong"."""
     import torch
     shard = importlib.import_module("sigmod-2018_amd.shard")
     ops = shard.RhjOps(rhj)
@@ -369,7 +413,9 @@ def run_strong(args, w, rhj, world, rank, backend, dist):
     if gather:
         check_properties(R, S, full, M, w)                 # canonical order, every S row once, on every rank
     if rank == 0:
-        cr, cs = info["tuples"]
+        lo, hi = info["range"]
+        share = (hi - lo) / float(1 << w["bits"])
+        cr, cs = int(w["nR"] * share), int(w["nS"] * share)           # (equal-width ranges of uniform keys)
         lp = info["local_pairs"]
         probe_bytes = 16 * (cr + cs) + 16 * lp
         ms_probe = st["ms_probe"]
@@ -379,7 +425,7 @@ def run_strong(args, w, rhj, world, rank, backend, dist):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": w["name"], "id": args.workload, "nR": w["nR"], "nS": w["nS"], "radix_bits": w["bits"],
-                          "matches": M, "parallelism": "bucket ranges over %d rank(s)%s" % (
+                          "matches": M, "parallelism": "equal-width bucket ranges over %d rank(s), one ranged join call per rank%s" % (
                               world, ", exact-size all-gather-v of the pair lists" if gather else ", pair lists kept sharded"),
                           "rank0_range": list(info["range"]), "rank0_tuples": [cr, cs], "pairs_per_rank": info["counts"]},
                "roofline": {"bound": "hbm", "kernel": "probe kernel of rank 0's bucket range", "achieved": probe_bytes / (ms_probe * 1e-3) / 1e9 if ms_probe > 0 else 0.0,

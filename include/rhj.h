@@ -228,6 +228,14 @@ int rhj_filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n,
  * the concatenation over the ranks' ranges is the canonical result.  Returns 1 (and the count needed)
  * when capacity was too small. */
 int rhj_bucket_histogram_device(const rhj_tuple *d_in, uint64_t n, uint64_t *d_hist);
+/* One rank's share in ONE call: the canonical result restricted to the buckets [bucket_lo, bucket_hi) of the current radix,
+ * with the relations handed over whole — the join's first partition pass drops the other ranks' buckets while it reads
+ * them (one read of each relation per rank; no selection pass, no host round trip in front of the join).  Same return
+ * values as rhj_join_device; -3 when the pair order was left to the library (RHJ_ORDER=any: bucket numbers are the
+ * caller's radix). */
+int rhj_join_device_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS,
+                          uint32_t bucket_lo, uint32_t bucket_hi,
+                          rhj_result_tuple *d_out, uint64_t out_capacity, uint64_t *matches);
 int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t bucket_lo, uint32_t bucket_hi,
                                    rhj_tuple *d_out, uint64_t capacity, uint64_t *count);
 
@@ -243,6 +251,7 @@ int  rhj_register_relation_map(const rhj_relation_map *map, int num_relations);
 int  rhj_unregister_relation_map(const rhj_relation_map *map, int num_relations);
 int  rhj_registered_columns(void);     /* registered columns / pinned host ranges right now */
 int  rhj_pinned_ranges(void);
+int  rhj_pin_refusals(void);      /* ranges of 64 KiB or more the host refused to pin (copied pageable instead) */
 void rhj_release(void);                /* drops the registry, every device buffer and the workspace */
 
 const rhj_stats *rhj_last_stats(void);

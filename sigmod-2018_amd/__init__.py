@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "rhj_set_radix_bits", "rhj_get_radix_bits", "rhj_set_empty_mode", "rhj_set_node_pairs", "rhj_set_device", "rhj_get_device",
     "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_subsplit", "rhj_set_small", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_partition_device", "rhj_filter_device",
     "rhj_register_relation_map", "rhj_unregister_relation_map", "rhj_registered_columns", "rhj_pinned_ranges",
-    "rhj_bucket_histogram_device", "rhj_select_bucket_range_device",
+    "rhj_bucket_histogram_device", "rhj_select_bucket_range_device", "rhj_join_device_range", "rhj_pin_refusals",
     "rhj_release", "rhj_last_stats", "rhj_version",
 ]
 # every symbol include/rhj_inter.h declares (device-resident intermediate results)
@@ -143,6 +143,8 @@ def load_library(path=None):
     L.rhj_unregister_relation_map.argtypes = [C.POINTER(RelationMap), C.c_int]
     L.rhj_bucket_histogram_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.rhj_select_bucket_range_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
+    L.rhj_join_device_range.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
+    L.rhj_pin_refusals.restype = C.c_int
     L.rhj_last_stats.restype = C.POINTER(Stats)
     L.rhj_version.restype = C.c_char_p
     return L
@@ -185,25 +187,31 @@ class RHJ:
         t = self.torch.from_numpy(rel.view(np.int64).reshape(-1, 2).copy())
         return t.to(self.dev)
 
-    def join_device(self, dR, dS, capacity=None, count_only=False):
-        """dR, dS: int64 tensors [n,2] (value,row_id).  Returns (pairs tensor [M,2], matches)."""
+    def join_device(self, dR, dS, capacity=None, count_only=False, bucket_range=None):
+        """dR, dS: int64 tensors [n,2] (value,row_id).  Returns (pairs tensor [M,2], matches).
+        bucket_range = (lo, hi): only the buckets [lo, hi) of the current radix (rhj_join_device_range: one rank's share of a
+        sharded join; the partition drops the other buckets while it reads the relations)."""
         torch = self.torch
         nR, nS = dR.shape[0], dS.shape[0]
         m = C.c_uint64(0)
-        if count_only:
-            rc = self.lib.rhj_join_device(dR.data_ptr(), nR, dS.data_ptr(), nS, None, 0, C.byref(m))
+
+        def call(out_ptr, cap):
+            if bucket_range is None:
+                rc = self.lib.rhj_join_device(dR.data_ptr(), nR, dS.data_ptr(), nS, out_ptr, cap, C.byref(m))
+            else:
+                rc = self.lib.rhj_join_device_range(dR.data_ptr(), nR, dS.data_ptr(), nS, int(bucket_range[0]), int(bucket_range[1]),
+                                                    out_ptr, cap, C.byref(m))
             if rc < 0:
                 raise RuntimeError("rhj_join_device failed (%d)" % rc)
+
+        if count_only:
+            call(None, 0)
             return None, m.value
         if capacity is None:
-            rc = self.lib.rhj_join_device(dR.data_ptr(), nR, dS.data_ptr(), nS, None, 0, C.byref(m))
-            if rc < 0:
-                raise RuntimeError("rhj_join_device failed (%d)" % rc)
+            call(None, 0)
             capacity = m.value
         out = torch.empty((max(capacity, 1), 2), dtype=torch.int64, device=self.dev)
-        rc = self.lib.rhj_join_device(dR.data_ptr(), nR, dS.data_ptr(), nS, out.data_ptr(), capacity, C.byref(m))
-        if rc < 0:
-            raise RuntimeError("rhj_join_device failed (%d)" % rc)
+        call(out.data_ptr(), capacity)
         return out[:min(m.value, capacity)], m.value
 
     def partition_device(self, d_in, bits=None):

@@ -15,7 +15,7 @@ struct RelArgs {                 // one relation through one partition pass
     uint32_t        *cnt;        // [tiles][bins] counts, then (after scan) start offsets
     uint64_t         n;
     uint32_t         tiles;
-    uint32_t         pad;
+    uint32_t         range_lo;   // sharded join: only buckets [range_lo, range_lo + range_span) of the join's radix are kept
     const uint8_t   *dig_in;     // pass 2 of the run form: this pass' digit per input tuple, written by pass 1
     uint8_t         *dig_out;    // pass 1 of the run form: the next pass' digit per output tuple
     // two-pass partition (run form): pass 1 partitions every tile in place and leaves a run table;
@@ -24,7 +24,7 @@ struct RelArgs {                 // one relation through one partition pass
     uint32_t         tiles1;     // pass-1 tiles
     uint32_t         group;      // pass-1 tiles per pass-2 tile
     uint32_t         groups;     // pass-2 tiles per pass-1 digit = ceil(tiles1 / group); tiles = bins1 * groups in pass 2
-    uint32_t         pad2;
+    uint32_t         range_span; // (0: every bucket — the ordinary join)
 };
 
 struct Unit {

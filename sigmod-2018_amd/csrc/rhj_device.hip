@@ -79,17 +79,19 @@ struct Ctx {
     int         no_sub = 1;          // 0: take the sub-split path where it applies (env RHJ_SUB=1, rhj_set_subsplit(1)); off by
                                      // default: on 100Mx100M@12 it measures 5.8 ms against 5.3 ms for the fused path (profiles/README.md r02)
     int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
+    bool        stamps = false;      // env RHJ_STAMPS (diagnostics build): in-kernel phase stamps of the fused kernel, read once at load time
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 512;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
     int         sub_lo = 0;          // pass-1 digit bits of the sub-split partition (0 = choose; env RHJ_SUB_LO)
     int         sub_k = -1;          // sub bits (-1 = choose from the relation sizes; env RHJ_SUB_K)
     uint32_t    sub_target = 3100;   // average build tuples per sub-bucket aimed at
+    uint32_t    range_lo = 0, range_span = 0;   // rhj_join_device_range: the buckets this call joins (span 0: all of them)
     int         cus = 256;           // compute units of the device (one fused workgroup each)
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     Buf sseqR, sseqS, segR, segS, sjunits, btotal, arena;
     void *pin = nullptr;            // small pinned block for read-backs
@@ -101,6 +103,7 @@ struct Ctx {
     struct Column { void *dev; size_t rows; };
     std::map<const void *, Column> columns;
     std::map<const void *, size_t> pinned;                       // hipHostRegister'ed host ranges (base -> bytes)
+    int pin_refusals = 0;                                        // ranges of 64 KiB or more the host refused to pin
     Buf fcol;                                                    // staging of an unregistered column (host Filter())
     std::multimap<size_t, void *> free_blocks;                  // rhj_dev_alloc: cached blocks by size
     std::map<void *, size_t> live_blocks;                       // rhj_dev_alloc: blocks handed out
@@ -126,6 +129,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_WIDE_ROW_IDS"))) g.wide_row_ids = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
+        g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
         if ((e = getenv("RHJ_SMALL_TILES"))) { g.small_tiles = (uint32_t)atoi(e); if (g.small_tiles > SM_MAX_TILES) g.small_tiles = SM_MAX_TILES; }
         if ((e = getenv("RHJ_SUB"))) g.no_sub = !atoi(e);
@@ -180,6 +184,7 @@ int ctx_init()
                                 (const void *)k_join_fused<true, false>, (const void *)k_join_fused<true, true>};
         for (const void *k : fused)
             HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_join_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_small_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(PT_MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
@@ -217,7 +222,7 @@ size_t scatter_lds_bytes(int bits)
 size_t scatter_runs_lds_bytes(int bits)
 {
     const size_t bins = (size_t)1 << bits;
-    return (size_t)SR_TILE * 16 + (PT_WAVES + 3) * bins * 4 + (PT_BLOCK / 64 + 2) * 8 + (2 * PT_MAX_GROUP + 1) * 4 + 16;
+    return (size_t)SR_TILE * 16 + (PT_WAVES + 3) * bins * 4 + (PT_BLOCK / 64 + 2) * 8 + 2 * (SR_RUNOFF + PT_MAX_GROUP) * 4 + 16;   // (run tables double-buffered)
 }
 
 // one stable pass over both relations (radix bits <= 8): per-tile histogram, scan, LDS-staged scatter
@@ -427,6 +432,8 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     if (ensure(g.partR, nR * sizeof(rhj_tuple)) || ensure(g.partS, nS * sizeof(rhj_tuple))) return -1;
     ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0, nullptr, nullptr};
     ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0, nullptr, nullptr};
+    const bool ranged = g.range_span != 0;                // a rank's share of a sharded join: the partition drops the other buckets
+    for (int i = 0; i < 2; ++i) { ps.r[i].range_lo = g.range_lo; ps.r[i].range_span = g.range_span; }
     ps.tmp[0] = ps.tmp[1] = nullptr;
     if (bits > PT_MAX_BITS) {
         if (ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple))) return -1;
@@ -493,8 +500,8 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     // no host memset, no total kernel, no read-back copy (rhj_small.hip.h)
     bool partitioned = false;      // the small path partitioned and planned, but some bucket needs the tiled path
     const uint32_t stilesR = (uint32_t)((nR + SM_TILE - 1) / SM_TILE), stilesS = (uint32_t)((nS + SM_TILE - 1) / SM_TILE);
-    if (want_fused && bits <= PT_MAX_BITS && !g.no_small && stilesR <= g.small_tiles && stilesS <= g.small_tiles &&
-        !getenv("RHJ_STAMPS")) {
+    if (want_fused && bits <= PT_MAX_BITS && !g.no_small && !ranged && stilesR <= g.small_tiles && stilesS <= g.small_tiles &&
+        !g.stamps) {
         const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;
         const uint64_t status_words = unit_bound + 1 + 8;                 // 8 ticket words in front
         RelArgs a0 = ps.r[0], a1 = ps.r[1];
@@ -502,7 +509,8 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         if (ensure(g.cntR, (size_t)a0.tiles * 256 * 4) || ensure(g.cntS, (size_t)a1.tiles * 256 * 4) ||
             ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
             ensure(g.status, status_words * 8 + 64) ||
-            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
+            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
+            ensure(g.walk, (unit_bound + 1) * sizeof(FjWalkItem)))
             return -1;
         a0.cnt = (uint32_t *)g.cntR.p; a1.cnt = (uint32_t *)g.cntS.p;
         FusedArgs fa;
@@ -510,11 +518,11 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.pad = 0;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits;
         fa.unit_bound = unit_bound;
         fa.host_summary = (uint64_t *)g.pin;
         fa.dbg = nullptr;
-        fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p;
+        fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p; fa.walk = (FjWalkItem *)g.walk.p;
         const uint32_t fused_lds = LDS_BUDGET - FJ_LDS_EXTRA;
         if (use_ctx_out) {
             const uint64_t guess = (nR > nS ? nR : nS) + 1024;
@@ -542,10 +550,12 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
                 RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             else
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);   // returns at once when no unit needs it
             RHJ_STAGE(ST_END);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;                                // written by the join kernel's last workgroup (system-scope stores)
+            if (plan.fused_ok && plan.matches == FJ_NO_TOTAL) { fprintf(stderr, "rhj: fused join left no match total (chained scan incomplete)\n"); return -1; }
             if (!plan.fused_ok) { partitioned = true; break; }
             small_done = true;
             M = plan.matches;
@@ -592,19 +602,20 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;
         if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
             ensure(g.status, (unit_bound + 1) * 8 + 64) ||
-            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
+            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
+            ensure(g.walk, (unit_bound + 1) * sizeof(FjWalkItem)))
             return -1;
         FusedArgs fa;
         fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
         fa.status = (uint64_t *)g.status.p + 8;               // words 0..7 hold the ticket
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.pad = 0;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits;
         fa.unit_bound = unit_bound;
         fa.host_summary = nullptr;
         fa.dbg = nullptr;
-        fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p;
-        if (getenv("RHJ_STAMPS")) {                           // diagnostic runs only
+        fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p; fa.walk = (FjWalkItem *)g.walk.p;
+        if (g.stamps) {                                       // diagnostic runs only
             if (ensure(g.dbg, (unit_bound + 1) * 64)) return -1;
             fa.dbg = (uint64_t *)g.dbg.p;
         }
@@ -638,11 +649,13 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
                     RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             }
+            RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);   // returns at once when no unit needs it
             RHJ_STAGE(ST_END);
             HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;
+            if (plan.fused_ok && plan.matches == FJ_NO_TOTAL && !g.ablate) { fprintf(stderr, "rhj: fused join left no match total (chained scan incomplete)\n"); return -1; }
             if (!plan.fused_ok) {
                 // a bucket needs the tiled path, which reads 16-byte tuples: partition again wide if this one was narrow
                 if (bits > PT_MAX_BITS && !force_wide && !plan.wide_row_ids) { *overflow = true; return 0; }
@@ -931,7 +944,7 @@ static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *
 {
     bool overflow = false;
     SubGeom geo;
-    if (nR && nS && nR < (1ull << 32) && nS < (1ull << 32) && !g.wide_row_ids && sub_geometry(g.bits, nR, nS, &geo)) {
+    if (nR && nS && nR < (1ull << 32) && nS < (1ull << 32) && !g.wide_row_ids && !g.range_span && sub_geometry(g.bits, nR, nS, &geo)) {
         if (ctx_init()) return -1;
         const float keep_h2d = g.stats.ms_h2d;
         memset(&g.stats, 0, sizeof(g.stats));
@@ -1030,9 +1043,7 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
 
 extern "C" {
 
-static std::recursive_mutex g_api_mutex;
-void rhj_api_lock(void) { g_api_mutex.lock(); }
-void rhj_api_unlock(void) { g_api_mutex.unlock(); }
+// (rhj_api_lock / rhj_api_unlock: rhj_host.cpp)
 
 int rhj_set_radix_bits(int bits)
 {
@@ -1066,6 +1077,12 @@ int rhj_debug_small_stamps(uint64_t *host)
 {
     RhjApiLock api_lock;
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sm_dbg), sizeof(uint64_t) * 4 * 2048) == hipSuccess ? 0 : -1;
+}
+/* diagnostics build only: phase stamps of pass 2's workgroups (tools/exp_sr_stamps.py) */
+int rhj_debug_sr_stamps(uint64_t *host)
+{
+    RhjApiLock api_lock;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sr_dbg), sizeof(uint64_t) * 256 * 16) == hipSuccess ? 0 : -1;
 }
 /* diagnostics build only: rate of random 16-byte gathers from per-workgroup regions (tools/gather_bench.py) */
 int rhj_debug_gather_bench(uint32_t region_elems, uint32_t rounds, uint32_t stream_per_round, uint32_t wgs, float *ms)
@@ -1116,6 +1133,29 @@ int rhj_join_device(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uin
     RhjApiLock api_lock;
     uint64_t m = 0;
     const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, false, nullptr, &m);
+    if (matches) *matches = m;
+    return rc;
+}
+
+/* One rank's share of a join sharded by bucket range (bucket b of R only meets bucket b of S, rhjoin.c:42-57):
+ * the canonical result restricted to the buckets [bucket_lo, bucket_hi) of the current radix.  The first partition pass
+ * drops the other buckets' tuples while it reads the relations — one read of each relation, no selection pass and no
+ * host round trip in front of the join; the concatenation of the ranks' results in range order is the canonical result. */
+int rhj_join_device_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, uint32_t bucket_lo, uint32_t bucket_hi,
+                          rhj_result_tuple *d_out, uint64_t out_capacity, uint64_t *matches)
+{
+    RhjApiLock api_lock;
+    if (matches) *matches = 0;
+    if (g.order_any) { fprintf(stderr, "rhj_join_device_range: bucket numbers belong to the caller's radix; not with RHJ_ORDER=any\n"); return -3; }
+    const uint32_t bins = 1u << g.bits;
+    if (bucket_hi > bins) bucket_hi = bins;
+    if (bucket_lo >= bucket_hi) return 0;                     // an empty range joins nothing
+    uint64_t m = 0;
+    const bool whole = bucket_lo == 0 && bucket_hi == bins;
+    g.range_lo = bucket_lo;
+    g.range_span = whole ? 0u : bucket_hi - bucket_lo;        // the whole radix is the ordinary join (small path and all)
+    const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, false, nullptr, &m);
+    g.range_lo = 0; g.range_span = 0;
     if (matches) *matches = m;
     return rc;
 }
@@ -1219,7 +1259,7 @@ void rhj_release(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.sseqR, &g.sseqS, &g.segR, &g.segS, &g.sjunits, &g.btotal, &g.arena, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);
@@ -1277,65 +1317,25 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
         }
     }
     HIP_TRY(hipEventRecord(g.ev_x[2], g.stream));
-    const uint64_t nblk = (M + blk - 1) / blk;
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads > 8) nthreads = 8;
     if (nthreads < 1 || M * sizeof(rhj_result_tuple) < ((size_t)8 << 20)) nthreads = 1;
-    // pairs [first, first + cnt) of the result, in staging block `src`, into the nodes
-    auto move = [&](const char *src, uint64_t first, uint64_t cnt) {
-        while (cnt) {
-            const uint64_t node = first / node_pairs, at = first % node_pairs;
-            const uint64_t take = cnt < node_pairs - at ? cnt : node_pairs - at;
-            memcpy(nodes[(size_t)node] + at * sizeof(rhj_result_tuple), src, take * sizeof(rhj_result_tuple));
-            src += take * sizeof(rhj_result_tuple); first += take; cnt -= take;
-        }
+    // the ring protocol and the mover threads are host-only code (rhj_host.cpp: rhj_move_blocks, built and run under the
+    // sanitizers on the CPU); this side only starts the copy of a block and waits for it
+    struct Copy { const rhj_result_tuple *d_out; uint64_t M, blk; } cp = {d_out, M, blk};
+    auto issue = [](void *c, uint64_t b) -> int {
+        const Copy *k = (const Copy *)c;
+        const uint64_t cnt = k->M - b * k->blk < k->blk ? k->M - b * k->blk : k->blk;
+        if (hipMemcpyAsync(g.pin_ring[b % RING], k->d_out + b * k->blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream) != hipSuccess) return -1;
+        return hipEventRecord(g.ev_ring[b % RING], g.stream) == hipSuccess ? 0 : -1;
     };
-    auto issue = [&](uint64_t b) -> int {
-        const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
-        HIP_TRY(hipMemcpyAsync(g.pin_ring[b % RING], d_out + b * blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipEventRecord(g.ev_ring[b % RING], g.stream));
-        return 0;
-    };
-    // mover threads live for the whole call: thread t moves the t-th slice of every block as soon as the block has landed
-    std::vector<std::atomic<int>> ready((size_t)nblk), done((size_t)nblk);
-    for (uint64_t b = 0; b < nblk; ++b) { ready[(size_t)b].store(0); done[(size_t)b].store(0); }
-    std::atomic<int> abort_flag{0};
-    auto worker = [&](unsigned t) {
-        for (uint64_t b = 0; b < nblk; ++b) {
-            while (!ready[(size_t)b].load(std::memory_order_acquire)) {
-                if (abort_flag.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
-            }
-            const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
-            const uint64_t per = (cnt + nthreads - 1) / nthreads, o = (uint64_t)t * per;
-            if (o < cnt) move((const char *)g.pin_ring[b % RING] + o * sizeof(rhj_result_tuple), b * blk + o, cnt - o < per ? cnt - o : per);
-            done[(size_t)b].fetch_add(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> pool;
-    if (nthreads > 1)
-        for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
-    int rc_copy = 0;
-    for (uint64_t b = 0; b < nblk && b < RING - 1 && !rc_copy; ++b) rc_copy = issue(b);
-    for (uint64_t b = 0; b < nblk && !rc_copy; ++b) {
-        if (b + RING - 1 < nblk) {
-            // the slot of block b + RING - 1 held block b - 1: wait until every mover is through with it
-            if (b > 0 && nthreads > 1)
-                while (done[(size_t)(b - 1)].load(std::memory_order_acquire) < (int)nthreads) std::this_thread::yield();
-            rc_copy = issue(b + RING - 1);
-            if (rc_copy) break;
-        }
-        if (hipEventSynchronize(g.ev_ring[b % RING]) != hipSuccess) { rc_copy = -1; break; }
-        if (nthreads == 1) {
-            const uint64_t cnt = M - b * blk < blk ? M - b * blk : blk;
-            move((const char *)g.pin_ring[b % RING], b * blk, cnt);
-        } else {
-            ready[(size_t)b].store(1, std::memory_order_release);
-        }
+    auto landed = [](void *, uint64_t b) -> int { return hipEventSynchronize(g.ev_ring[b % RING]) == hipSuccess ? 0 : -1; };
+    char *staging[RING];
+    for (int i = 0; i < RING; ++i) staging[i] = (char *)g.pin_ring[i];
+    if (rhj_move_blocks(M, sizeof(rhj_result_tuple), node_pairs, nodes.data(), blk, RING, staging, nthreads, issue, landed, &cp)) {
+        (void)hipGetLastError();
+        return -1;
     }
-    if (rc_copy) abort_flag.store(1);
-    for (auto &th : pool) th.join();
-    if (rc_copy) return -1;
     HIP_TRY(hipEventRecord(g.ev_x[3], g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     g.stats.ms_d2h = ev_ms(g.ev_x[2], g.ev_x[3]);
@@ -1353,13 +1353,24 @@ static const uint64_t *registered_column(const uint64_t *host_col, uint64_t rows
 // Pin [base, base + bytes) for the H2D copy (relation_map.c:28-50: the columns of a relation are one
 // contiguous block of the PROT_READ | MAP_PRIVATE file mapping, hence the read-only flag first).
 // Returns whether the range is pinned now; a range that cannot be pinned is copied pageable.
+// hipHostRegister of a host range the library copies columns from.  A read-only file mapping (InitRelationMap's
+// PROT_READ | MAP_PRIVATE block) takes the read-only flag; memory the caller owns takes either.  Which flag the host
+// accepted is traced (RHJ_TRACE=1) and counted: rhj_pinned_ranges(), rhj_pin_refusals().
 static bool pin_range(const void *base, size_t bytes)
 {
+    static const bool trace = getenv("RHJ_TRACE") != nullptr;
     if (bytes < (64u << 10)) return false;                              // registration costs more than it saves
     if (g.pinned.count(base)) return true;
+    const char *how = "read-only";
     hipError_t e = hipHostRegister((void *)base, bytes, hipHostRegisterReadOnly);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister((void *)base, bytes, hipHostRegisterDefault); }
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (e != hipSuccess) { (void)hipGetLastError(); how = "default"; e = hipHostRegister((void *)base, bytes, hipHostRegisterDefault); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ++g.pin_refusals;
+        if (trace) fprintf(stderr, "rhj-trace:   hipHostRegister refused %zu bytes at %p (%s): pageable copy\n", bytes, base, hipGetErrorString(e));
+        return false;
+    }
+    if (trace) fprintf(stderr, "rhj-trace:   hipHostRegister(%s) pinned %zu bytes at %p\n", how, bytes, base);
     g.pinned[base] = bytes;
     return true;
 }
@@ -1435,6 +1446,7 @@ int rhj_unregister_relation_map(const rhj_relation_map *map, int num_relations)
 
 int rhj_registered_columns(void) { return (int)g.columns.size(); }
 int rhj_pinned_ranges(void) { return (int)g.pinned.size(); }
+int rhj_pin_refusals(void) { return g.pin_refusals; }
 
 // Filter on a host column (its registered device copy, or uploaded for this call) with an optional
 // host row-id indirection vector; ids come back in `node_ids`-sized chunks.

@@ -579,20 +579,23 @@ void Merge(rhj_inter_res **head, rhj_inter_res **node, int rel_num)             
     free(victim);
 }
 
-void MergeInterNodes(rhj_inter_res **inter)                                         // inter_res.c:265-284
+static bool inter_active(const rhj_inter_res *node, int rel) { return node->data->table[rel] != nullptr; }
+
+// inter_res.c:265-284.  A relation that is active in a node AND in a later node ties the two together: the later node is
+// merged into the earlier one through that relation (Merge unlinks it), for every node of the list in turn.  The walk over
+// the later nodes steps past the node that follows a merged one without testing it in the same sweep — as the reference's
+// does; which node meets which first decides the row order of the merged tables, so the sweep order is part of the result.
+void MergeInterNodes(rhj_inter_res **inter)
 {
     RhjApiLock api_lock;
-    if ((*inter)->next == nullptr) return;
-    for (int i = 0; i < (*inter)->num_of_relations; i++) {
-        rhj_inter_res *temp = (*inter);
-        if ((*inter)->data->table[i] == nullptr) continue;
-        while (temp->next != nullptr) {
-            if (temp->next->data->table[i] != nullptr) Merge(inter, &temp, i);
-            temp = temp->next;
-            if (temp == nullptr) break;
+    for (rhj_inter_res **owner = inter; *owner != nullptr && (*owner)->next != nullptr; owner = &(*owner)->next) {
+        for (int rel = 0; rel < (*owner)->num_of_relations; ++rel) {
+            if (!inter_active(*owner, rel)) continue;
+            for (rhj_inter_res *before = *owner; before != nullptr && before->next != nullptr; before = before->next)
+                if (inter_active(before->next, rel)) Merge(owner, &before, rel);    // before->next is gone afterwards
         }
+        if ((*owner)->next == nullptr) break;
     }
-    if ((*inter)->next != nullptr) MergeInterNodes(&(*inter)->next);
 }
 
 void CalculateQueryResults(rhj_inter_res *inter, rhj_relation_map *map, rhj_batch_listnode *query)   // inter_res.c:320-339
@@ -765,45 +768,57 @@ int rhj_column_stats_device(const uint64_t *d_col, uint64_t n, uint64_t *l, uint
     return 0;
 }
 
+// A relation file (relation_map.c:21-50): two 64-bit words — rows, columns — then the columns one after the other.
+struct RelationFileHeader { uint64_t rows, columns; };
+
+// maps a relation file read-only; the descriptor stays open in the list node as in the reference (FreeRelationList closes it)
+static const RelationFileHeader *map_relation_file(rhj_relation_listnode *node, size_t *bytes)
+{
+    node->fd = open(node->filename, O_RDONLY);
+    if (node->fd < 0) return nullptr;
+    struct stat info;
+    if (fstat(node->fd, &info) != 0 || (size_t)info.st_size < sizeof(RelationFileHeader)) return nullptr;
+    void *base = mmap(nullptr, (size_t)info.st_size, PROT_READ, MAP_PRIVATE, node->fd, 0);
+    if (base == MAP_FAILED) { fprintf(stderr, "rhj: cannot map relation file %s\n", node->filename); return nullptr; }
+    const RelationFileHeader *h = static_cast<const RelationFileHeader *>(base);
+    if (h->columns != 0 && (size_t)info.st_size - sizeof(RelationFileHeader) < h->rows * h->columns * sizeof(uint64_t)) {
+        fprintf(stderr, "rhj: relation file %s is shorter than its header says\n", node->filename);
+        return nullptr;
+    }
+    *bytes = (size_t)info.st_size;
+    return h;
+}
+
 int InitRelationMap(rhj_relation_listnode *head, rhj_relation_map *rel_map)           // relation_map.c:13-88
 {
     RhjApiLock api_lock;
-    int i = 0;
     TRACE("InitRelationMap begins");
-    while (head != nullptr) {
-        struct stat sb;
-        if ((head->fd = open(head->filename, O_RDONLY)) == -1) return 1;
-        if (fstat(head->fd, &sb) == -1) return 1;
-        uint64_t *map = (uint64_t *)mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, head->fd, 0);
-        if (map == MAP_FAILED) {
-            printf("map failed \n");
-            return 1;
-        }
-        rel_map[i].num_tuples = map[0];
-        rel_map[i].num_columns = map[1];
-        rel_map[i].col_stats = (rhj_column_stats *)malloc(rel_map[i].num_columns * sizeof(rhj_column_stats));
-        rel_map[i].columns = (uint64_t **)malloc(rel_map[i].num_columns * sizeof(uint64_t *));
-        map = map + 2;
-        for (uint64_t j = 0; j < rel_map[i].num_columns; ++j) {
-            rel_map[i].columns[j] = map;
-            map += rel_map[i].num_tuples;
-            // the device copy every later operator reads (registered until FreeRelationMap; the relation's
-            // columns are one block of the file mapping, pinned for the copy), and the statistics computed on it
-            if (rhj_dev_register_column(rel_map[i].columns[j], rel_map[i].num_tuples, j == 0 ? (const void *)rel_map[i].columns[0] : nullptr,
-                                        rel_map[i].num_columns * rel_map[i].num_tuples * 8))
+    int loaded = 0;
+    uint64_t most_rows = 0;
+    for (rhj_relation_listnode *node = head; node != nullptr; node = node->next, ++loaded) {
+        size_t bytes = 0;
+        const RelationFileHeader *file = map_relation_file(node, &bytes);
+        if (file == nullptr) return 1;
+        rhj_relation_map &rm = rel_map[loaded];
+        rm.num_tuples = file->rows;
+        rm.num_columns = file->columns;
+        rm.col_stats = (rhj_column_stats *)malloc(rm.num_columns * sizeof(rhj_column_stats));
+        rm.columns = (uint64_t **)malloc(rm.num_columns * sizeof(uint64_t *));
+        uint64_t *first = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(file + 1));
+        for (uint64_t c = 0; c < rm.num_columns; ++c) {
+            rm.columns[c] = first + c * rm.num_tuples;
+            // the device copy every later operator reads (registered until FreeRelationMap; the relation's columns are one
+            // block of the file mapping, pinned for the copy), and the optimiser's statistics computed on it
+            if (rhj_dev_register_column(rm.columns[c], rm.num_tuples, c == 0 ? (const void *)first : nullptr, rm.num_columns * rm.num_tuples * 8))
                 die("InitRelationMap");
-            const DevColumn d_col(&rel_map[i], (int)j);
-            rhj_column_stats *st = &rel_map[i].col_stats[j];
-            st->f = (double)rel_map[i].num_tuples;
-            if (rhj_column_stats_device(d_col, rel_map[i].num_tuples, &st->l, &st->u, &st->d)) die("InitRelationMap");
+            rhj_column_stats *st = &rm.col_stats[c];
+            st->f = (double)rm.num_tuples;
+            if (rhj_column_stats_device(DevColumn(&rm, (int)c), rm.num_tuples, &st->l, &st->u, &st->d)) die("InitRelationMap");
         }
-        head = head->next;
-        i++;
-        TRACE("InitRelationMap: relation %d loaded", i - 1);
+        if (rm.num_tuples > most_rows) most_rows = rm.num_tuples;
+        TRACE("InitRelationMap: relation %d loaded", loaded);
     }
-    uint64_t most = 0;
-    for (int k = 0; k < i; ++k) most = rel_map[k].num_tuples > most ? rel_map[k].num_tuples : most;
-    if (most) (void)rhj_dev_reserve(most);              // the joins' workspace for inputs of the base relations' size
+    if (most_rows) (void)rhj_dev_reserve(most_rows);    // the joins' workspace for inputs of the base relations' size
     return 0;
 }
 

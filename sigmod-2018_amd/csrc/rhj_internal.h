@@ -33,6 +33,10 @@ int   rhj_dev_join(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint
  * host threads are serialised instead of racing on the workspace, the registries and the stream. */
 void rhj_api_lock(void);
 void rhj_api_unlock(void);
+/* rhj_host.cpp: elements that arrive through a ring of staging blocks -> result nodes, by several host threads */
+int rhj_move_blocks(uint64_t total, uint64_t elem, uint64_t node_elems, char *const *nodes, uint64_t blk, int ring,
+                    char *const *staging, unsigned threads, int (*issue)(void *ctx, uint64_t b),
+                    int (*wait)(void *ctx, uint64_t b), void *ctx);
 
 /* device-resident side of the reference's entry points (rhj_inter.hip), called by rhj_abi.c */
 rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS);

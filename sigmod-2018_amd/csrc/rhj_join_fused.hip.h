@@ -38,21 +38,34 @@ constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
 constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
 constexpr uint32_t FJ_GROUPS = FJ_SPAN / 256;   // a group = the 256 tuples one wave counts in one batch
+constexpr uint64_t FJ_NO_TOTAL = ~0ull;         // PlanSummary::matches when the last unit's inclusive prefix was never published
 
 struct FusedArgs {
     JoinArgs  j;
     uint8_t  *stash_cnt;      // [nR + nS] matches per probe tuple, saturating at 255
     uint64_t *stash_row;      // [nR + nS] build row id of the first match
     uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
-    uint32_t *ticket;         // word 0: next unit; word 1: workgroups that are through (the last one out leaves the match total)
+    uint32_t *ticket;         // word 0: next unit; word 1: workgroups that are through (the last one out leaves the match total);
+                              // word 2: entries of the walk list; word 3: k_join_walk's own ticket
     uint64_t  nR;
     uint32_t  allow_resident;
-    uint32_t  pad;
+    uint32_t  radix_bits;     // the join's radix width (the bits every key of a bucket shares)
     uint64_t  unit_bound;     // status words there are
     uint64_t *host_summary;   // pinned host block that receives the plan summary (with the match total) at the end, or null
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
     uint64_t *ovf;            // [grid][2][FJ_OVF_CAP] build row ids of second and later matches (per workgroup, double-buffered)
     uint32_t *ovf_base;       // [grid][2][FJ_SPAN / 256][16] first overflow slot of (256-tuple group, match ordinal)
+    struct FjWalkItem *walk;  // [unit_bound] units whose pairs k_join_walk writes (the stash cannot describe them)
+};
+
+// A unit the streaming emit cannot serve — a tag collision beside two or more matches, more than 16 matches of one
+// tuple, an overflow stash that ran full — is handed to k_join_walk, which rebuilds the index and walks it again.
+struct FjWalkItem {
+    uint32_t unit;
+    uint32_t flags;           // bit 0: the unit's build tuples were LDS-resident in k_join_fused (its stash keeps runs for multi-match
+                              // tuples); bit 1: k_join_fused hashed with FjHashT<true> — the stash's "a tag hit was a foreign key"
+                              // bit is a statement about THAT hash's tags, so the walk must index with the same one
+    uint64_t base;            // first output position of the unit (its look-back is done)
 };
 
 
@@ -70,14 +83,43 @@ struct FusedArgs {
 // the hits: no pointer chasing and no loop whose trip count is the longest chain of the wave (the
 // linked chains spent 2/3 of the probe's vector instructions there).  Slots longer than 8 continue
 // window by window.
-struct FjIndex {
+// Two hashes behind slot and tag.  H32 (kernels that may keep build tuples LDS-resident: C2, C4, the contest's joins): ONE
+// 32-bit multiply of the key without the radix bits its bucket shares, the upper key word folded in by a rotation; slot =
+// upper half scaled to hs by a 24-bit multiply (hs < 2^16), tag = lower half after one xor-shift.  mix64's two 64-bit
+// multiplies are eight quarter-rate 32-bit ones, paid in the build's count pass, its fill pass and the probe: A/B (own process
+// per build, r03a) c3b14 -3 %, C2 -7 %, C4 -1 % of the kernel.  The gather kernels (C3 at 12 bits) keep mix64: their time is
+// the gathers', and with the short hash they measured 3 % SLOWER (2.47 -> 2.55 ms, r03c; slot by __umulhi the same).
+// Results never depend on the hash: every candidate is verified against the 64-bit key.
+template <bool H32> struct FjHashT;
+template <> struct FjHashT<false> {
+    typedef uint64_t type;
+    static __device__ __forceinline__ type hash(uint64_t key, uint32_t) { return mix64(key); }
+    static __device__ __forceinline__ uint32_t slot(type h, uint32_t hs) { return __umulhi((uint32_t)(h >> 32), hs); }
+    static __device__ __forceinline__ uint32_t tag(type h) { return min((uint32_t)(h >> 16) & 0xffffu, 0xfffdu) + 1u; }
+};
+template <> struct FjHashT<true> {
+    typedef uint32_t type;
+    static __device__ __forceinline__ type hash(uint64_t key, uint32_t bits)
+    {
+        const uint32_t x = (uint32_t)(key >> bits) ^ __builtin_rotateleft32((uint32_t)(key >> 32) >> bits, 16);
+        const uint32_t h = x * 0x9e3779b1u;
+        return h ^ (h >> 15);
+    }
+    static __device__ __forceinline__ uint32_t slot(type h, uint32_t hs) { return __umul24(h >> 16, hs) >> 16; }
+    static __device__ __forceinline__ uint32_t tag(type h) { return min(h & 0xffffu, 0xfffdu) + 1u; }
+};
+template <bool H32>
+struct FjIndexT {
+    typedef typename FjHashT<H32>::type hash_t;
     uint32_t *ent;       // [bc + 8]
     uint32_t *dirw;      // [(hs + 3) / 2]
     uint32_t  hs;
-    __device__ __forceinline__ uint32_t slot(uint64_t h) const { return __umulhi((uint32_t)(h >> 32), hs); }
+    uint32_t  bits;      // the join's radix bits: shared by every key of the bucket
+    __device__ __forceinline__ hash_t hash(uint64_t key) const { return FjHashT<H32>::hash(key, bits); }
+    __device__ __forceinline__ uint32_t slot(hash_t h) const { return FjHashT<H32>::slot(h, hs); }
+    static __device__ __forceinline__ uint32_t tag(hash_t h) { return FjHashT<H32>::tag(h); }
     __device__ __forceinline__ uint32_t H(uint32_t j) const { return reinterpret_cast<const uint16_t *>(dirw)[j]; }
 };
-__device__ __forceinline__ uint32_t fj_tag(uint64_t h) { return min((uint32_t)(h >> 16) & 0xffffu, 0xfffdu) + 1u; }
 
 // Partitioned relations as the fused kernel sees them: rhj_tuple (16 B), or — N32: the partition found every row id
 // below 2^32 and wrote Tuple12 — 12 bytes per tuple.  Whole tuple as {key lo, key hi, row id lo, row id hi}.
@@ -93,7 +135,8 @@ template <bool N32> __device__ __forceinline__ uint2 pt_load_key(const rhj_tuple
 }
 
 // hit mask of the first min(n, 8) entries of the window at `start`
-__device__ __forceinline__ uint32_t fj_window(const FjIndex &X, uint32_t start, uint32_t n, uint32_t tgs)
+template <class IX>
+__device__ __forceinline__ uint32_t fj_window(const IX &X, uint32_t start, uint32_t n, uint32_t tgs)
 {
     uint32_t e[8];
 #pragma unroll
@@ -107,12 +150,13 @@ __device__ __forceinline__ uint32_t fj_window(const FjIndex &X, uint32_t start, 
 
 // Per probe tuple: sn = window start | remaining slot length << 16, tm = tag << 16 | hit mask of the
 // current window.
-__device__ __forceinline__ void fj_lookup(const FjIndex &X, uint64_t key, bool ok, uint32_t &sn, uint32_t &tm)
+template <class IX>
+__device__ __forceinline__ void fj_lookup(const IX &X, uint64_t key, bool ok, uint32_t &sn, uint32_t &tm)
 {
-    const uint64_t h = mix64(key);
+    const auto h = X.hash(key);
     const uint32_t s = X.slot(h);
     const uint32_t d0 = X.H(s + 1u), n = ok ? X.H(s + 2u) - d0 : 0u;
-    const uint32_t tgs = fj_tag(h) << 16;
+    const uint32_t tgs = X.tag(h) << 16;
     sn = d0 | (n << 16);
     tm = tgs | fj_window(X, d0, n, tgs);
 }
@@ -120,7 +164,8 @@ __device__ __forceinline__ void fj_lookup(const FjIndex &X, uint64_t key, bool o
 // One round of the probe: every tuple that still has a candidate hands out its next one (pos[k], a
 // build position) — first from the window's hit mask, and when that is used up and the slot is longer
 // than the window, from the next window.  Returns whether any lane of the wave got a candidate.
-__device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V], uint32_t (&tm)[FJ_V], uint32_t (&pos)[FJ_V],
+template <class IX>
+__device__ __forceinline__ bool fj_round(const IX &X, uint32_t (&sn)[FJ_V], uint32_t (&tm)[FJ_V], uint32_t (&pos)[FJ_V],
                                          bool &last)
 {
     bool more = false;
@@ -161,8 +206,8 @@ __device__ __forceinline__ bool fj_round(const FjIndex &X, uint32_t (&sn)[FJ_V],
 // for the cooperative sort of long slots.
 constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
 constexpr int FJ_SMALL = 4;                           // batches of 4096 build tuples whose (slot, tag) words are kept for the fill pass
-template <bool RES, bool N32>
-__device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *part, uint64_t boff, uint32_t bc, uint4 *ltup,
+template <bool RES, bool N32, class IX>
+__device__ __forceinline__ void fj_build(const IX &X, const rhj_tuple *part, uint64_t boff, uint32_t bc, uint4 *ltup,
                                          uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -195,9 +240,9 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *part
                 const uint32_t i = i0 + k * FJ_BLOCK + tid;
                 if (i < bc) {
                     if (RES) ltup[i] = t[k];
-                    const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
+                    const auto h = X.hash(((uint64_t)t[k].y << 32) | t[k].x);
                     const uint32_t sl = X.slot(h);
-                    if (small) X.ent[i] = (sl << 16) | fj_tag(h);       // parked in the still unused entry array
+                    if (small) X.ent[i] = (sl << 16) | X.tag(h);       // parked in the still unused entry array
                     const uint32_t j = sl + 1u;
                     atomicAdd(&X.dirw[j >> 1], (j & 1u) ? 0x10000u : 1u);
                 }
@@ -290,8 +335,8 @@ __device__ __forceinline__ void fj_build(const FjIndex &X, const rhj_tuple *part
             for (int k = 0; k < FJ_V; ++k) {
                 const uint32_t i = i0 + k * FJ_BLOCK + tid;
                 if (i < bc) {
-                    const uint64_t h = mix64(((uint64_t)t[k].y << 32) | t[k].x);
-                    insert(X.slot(h), (fj_tag(h) << 16) | i);
+                    const auto h = X.hash(((uint64_t)t[k].y << 32) | t[k].x);
+                    insert(X.slot(h), (X.tag(h) << 16) | i);
                 }
             }
 #pragma unroll
@@ -397,8 +442,8 @@ struct FjOvf {
     uint32_t  gid;        // group of this wave in this batch
 };
 
-template <bool RES, bool OVF, bool N32>
-__device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather<N32> &G, const uint4 *ltup,
+template <bool RES, bool OVF, bool N32, class IX>
+__device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> &G, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
                                                uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
                                                const FjOvf &O)
@@ -467,12 +512,13 @@ __device__ __forceinline__ void fj_count_batch(const FjIndex &X, const FjGather<
 // run = start | cnt << 16 is what the emit pass needs when cnt >= 2 and the run is CLEAN (every entry a match: the
 // j-th match is entry start + j); fp = some entry of the run belongs to another key (a 16-bit tag collision inside
 // one slot) — with two or more matches beside it the unit takes the index-walking emit.
-__device__ __forceinline__ void fj_run_of(const FjIndex &X, uint64_t key, bool ok, uint32_t &start, uint32_t &len)
+template <class IX>
+__device__ __forceinline__ void fj_run_of(const IX &X, uint64_t key, bool ok, uint32_t &start, uint32_t &len)
 {
-    const uint64_t h = mix64(key);
+    const auto h = X.hash(key);
     const uint32_t s = X.slot(h);
     const uint32_t d0 = X.H(s + 1u), n = ok ? X.H(s + 2u) - d0 : 0u;
-    const uint32_t tg = fj_tag(h);
+    const uint32_t tg = X.tag(h);
     if (n <= 8u) {
         const uint32_t m = fj_window(X, d0, n, tg << 16);
         start = d0 + (m ? (uint32_t)__builtin_ctz(m) : 0u);
@@ -489,7 +535,8 @@ __device__ __forceinline__ void fj_run_of(const FjIndex &X, uint64_t key, bool o
 }
 
 constexpr uint32_t FJ_RUN_LOCK = 64;             // run entries verified lane by lane before the wave takes a long run together
-__device__ __forceinline__ void fj_count_res(const FjIndex &X, const uint4 *ltup, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
+template <class IX>
+__device__ __forceinline__ void fj_count_res(const IX &X, const uint4 *ltup, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
                                              uint32_t (&c)[FJ_V], uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
                                              uint32_t (&run)[FJ_V])
 {
@@ -718,8 +765,8 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
 // belongs to the tuple whose inclusive prefix is the first above o (binary search over the lanes by shuffles) and is
 // match o - (its exclusive prefix) of that tuple = entry start + that of its run — any number of matches per tuple at
 // 64 coalesced pairs per store (a lane walking its own 600-match chain wrote one pair per round).
-template <bool N32>
-__device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const FjIndex &X, const uint4 *ltup, uint32_t u, uint64_t base,
+template <bool N32, class IX>
+__device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, const uint4 *ltup, uint32_t u, uint64_t base,
                                             uint32_t *wsum, uint32_t *table, uint32_t *grab)
 {
     constexpr int V = FJ_V;
@@ -840,7 +887,6 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned long long *st = (unsigned long long *)f.status;
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
-    const uint64_t cap = a.out_capacity;
     const bool emitting = out != nullptr && FJ_ABLATE != 3;
     if ((a.summary->wide_row_ids == 0) != N32) return;                 // the other instantiation's launch does the join
     uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
@@ -876,9 +922,10 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     // build tuples go to LDS too when they fit beside the index (wave-uniform per unit)
     const bool RES = MAYRES && f.allow_resident && (size_t)bcp * 20 + (size_t)(hs0 + 3) / 2 * 4 + 64 <= lds_bytes;
     uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
-    FjIndex X;
+    FjIndexT<MAYRES> X;
     X.ent = tbl + (RES ? 4u * bcp : 0u);
     X.hs = hs0;
+    X.bits = f.radix_bits;
     X.dirw = X.ent + bcp + 8u;
     uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
     uint2 *srow = reinterpret_cast<uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
@@ -1010,11 +1057,111 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
         continue;
     }
-    // ---- phase 2: emit (general form: duplicates and tag collisions walk the index again)
-    uint64_t run = sh_base;
-#ifdef FJ_NO_WALK
-    continue;                                         // timing experiment: what the index-walking emit costs the kernel in registers
-#endif
+    // ---- this unit's pairs need the index walked again: k_join_walk, enqueued behind this kernel, writes them
+    if (threadIdx.x == 0) {
+        const uint32_t at = atomicAdd(f.ticket + 2, 1u);
+        f.walk[at] = FjWalkItem{u, (RES ? 1u : 0u) | (MAYRES ? 2u : 0u), sh_base};
+    }
+    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    }   // ticket loop
+
+    if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup
+        __syncthreads();
+        if (w == 0) {
+            const uint64_t excl = pend == 0 ? 0 : fj_lookback(st, pend, lane);
+            if (lane == 0) {
+                if (pend != 0) __hip_atomic_store(&st[pend], (2ull << 62) | (excl + pend_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_base = excl;
+            }
+        }
+        __syncthreads();
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+    }
+}
+
+template <bool MAYRES, bool N32>
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
+{
+    fj_body<MAYRES, N32>(f, lds_bytes);
+    // The last workgroup out leaves the match total = inclusive prefix of the last unit (every unit publishes one
+    // before it emits; nothing when the plan rejected the fused path: its unit list is the tiled one then).  Both
+    // row-id instantiations of a join are launched and either may run first: the one that returns at once finds the
+    // status words still clear or already complete, and the later launch's total is the one that stays.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // Release + acquire at agent scope on the counter: this workgroup's status words are out before it counts itself, and
+        // the last one to arrive sees everybody's (the workgroups run on eight XCDs with an L2 each).
+        if (__hip_atomic_fetch_add(f.ticket + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(f.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PlanSummary *sum = const_cast<PlanSummary *>(f.j.summary);
+            const uint64_t n = sum->units;
+            uint64_t total = 0;
+            if (sum->fused_ok && n && n <= f.unit_bound) {
+                const unsigned long long v = __hip_atomic_load((unsigned long long *)f.status + (n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // not an inclusive prefix: this launch did not run the units (the other row-id width's launch does and
+                // leaves its total behind this one) — or the chain is broken, and then the host must not take 0 for an answer
+                total = (v >> 62) == 2 ? (v & ((1ull << 62) - 1)) : FJ_NO_TOTAL;
+            }
+            sum->matches = total;
+            if (f.host_summary) {
+                const uint64_t *src = reinterpret_cast<const uint64_t *>(sum);
+                static_assert(sizeof(PlanSummary) % 8 == 0, "summary words");
+                for (uint32_t i = 0; i < sizeof(PlanSummary) / 8; ++i) {
+                    const uint64_t v = i == offsetof(PlanSummary, matches) / 8 ? total : src[i];
+                    __hip_atomic_store(f.host_summary + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
+}
+
+// ---- k_join_walk: the pairs of the units k_join_fused left on the walk list.  ALWAYS enqueued behind k_join_fused and
+// returns at once when the list is empty (no host round trip decides the launch).  With this code inside the fused kernel
+// — one 1024-thread function at the 128-VGPR cap — the foreign-key loops paid for its live values: 20 spilled VGPRs and
+// scratch on every launch (timing with the walk compiled out, profiles/README.md r02z: C3 -3.3 %, C2 -13 % of the kernel).
+// A listed unit's index is built again (same geometry, same residency decision as in k_join_fused), then:
+//   the first match comes from the stash (phase 1 kept its row id); further matches of a tuple are fetched in lockstep
+//   rounds over its slot; when no tag hit of the tuple was a foreign key (stash bit 7 clear) its first candidate IS that
+//   first match and is skipped unfetched.  Order: probe tuples in unit order, matches in slot order = descending build
+//   position (rhjoin.c:141-250).
+template <bool RES, bool N32, bool H32>
+__device__ __forceinline__ void fj_walk_unit(const FusedArgs &f, uint32_t lds_bytes, uint32_t *tbl, uint32_t u, uint64_t base,
+                                             uint32_t *wsum, uint32_t *sh_pick)
+{
+    const JoinArgs &a = f.j;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint4 *out = reinterpret_cast<uint4 *>(a.out);
+    const uint64_t cap = a.out_capacity;
+    const Unit un = a.units[u];
+    const uint32_t b = un.bucket;
+    const uint64_t cR = a.histR[b], cS = a.histS[b];
+    const bool flip = cR < cS;
+    const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
+    const rhj_tuple *prp = flip ? a.partS : a.partR;
+    const rhj_tuple *bdp = flip ? a.partR : a.partS;
+    const uint64_t bpos = flip ? a.psumR[b] : a.psumS[b];
+    const uint32_t bc = (uint32_t)(flip ? cR : cS);
+    const uint32_t bcp = (bc + 3u) & ~3u;
+    uint32_t hs0 = bc < 64u ? 64u : bc;               // (the geometry of fj_body)
+    {
+        const uint32_t room = (lds_bytes - 64u - 4u * bcp) / 2u - 2u;
+        if (hs0 > room) hs0 = room & ~1u;
+    }
+    uint4 *ltup = reinterpret_cast<uint4 *>(tbl);
+    FjIndexT<H32> X;                                  // the hash of the kernel that wrote this unit's stash
+    X.ent = tbl + (RES ? 4u * bcp : 0u);
+    X.hs = hs0;
+    X.bits = f.radix_bits;
+    X.dirw = X.ent + bcp + 8u;
+    const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
+    const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
+    FjGather<N32> G;
+    G.init(bdp, bpos, bc);
+    __syncthreads();                                  // the previous unit's index is no longer read
+    fj_build<RES, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(f.ovf + (size_t)blockIdx.x * 2 * FJ_OVF_CAP), wsum, sh_pick);
+    __syncthreads();
+    uint64_t run = base;
     // FJ_H batches per iteration; a wave's slice of the iteration is contiguous: order (wave, half,
     // round, lane).  FJ_H = 2 (more loads in flight, half the barriers) measured +11 % on the kernel:
     // it spills at the 128-VGPR limit of a 1024-thread workgroup.
@@ -1045,8 +1192,8 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 #pragma unroll
                 for (int k = 0; k < FJ_V; ++k) {
                     if (c[h][k] == 127u) {
-                        const uint64_t hh = mix64(((uint64_t)q[h][k].y << 32) | q[h][k].x);
-                        const uint32_t t = fj_tag(hh), sl = X.slot(hh);
+                        const auto hh = X.hash(((uint64_t)q[h][k].y << 32) | q[h][k].x);
+                        const uint32_t t = X.tag(hh), sl = X.slot(hh);
                         uint32_t n = 0;
                         for (uint32_t at = X.H(sl + 1u), end = X.H(sl + 2u); at < end; ++at) {
                             const uint32_t nd = X.ent[at];
@@ -1121,53 +1268,27 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             }
         }
     }
-    if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-    }   // ticket loop
-
-    if (pend != 0xffffffffu) {                        // last deferred emit of this workgroup
-        __syncthreads();
-        if (w == 0) {
-            const uint64_t excl = pend == 0 ? 0 : fj_lookback(st, pend, lane);
-            if (lane == 0) {
-                if (pend != 0) __hip_atomic_store(&st[pend], (2ull << 62) | (excl + pend_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh_base = excl;
-            }
-        }
-        __syncthreads();
-        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
-        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
-    }
 }
 
-template <bool MAYRES, bool N32>
-__global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_walk(FusedArgs f, uint32_t lds_bytes)
 {
-    fj_body<MAYRES, N32>(f, lds_bytes);
-    // The last workgroup out leaves the match total = inclusive prefix of the last unit (every unit publishes one
-    // before it emits; nothing when the plan rejected the fused path: its unit list is the tiled one then).  Both
-    // row-id instantiations of a join are launched and either may run first: the one that returns at once finds the
-    // status words still clear or already complete, and the later launch's total is the one that stays.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this thread's status words are out before it counts itself
-        if (__hip_atomic_fetch_add(f.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-            __hip_atomic_store(f.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            PlanSummary *sum = const_cast<PlanSummary *>(f.j.summary);
-            const uint64_t n = sum->units;
-            uint64_t total = 0;
-            if (sum->fused_ok && n && n <= f.unit_bound) {
-                const unsigned long long v = __hip_atomic_load((unsigned long long *)f.status + (n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 62) == 2) total = v & ((1ull << 62) - 1);
-            }
-            sum->matches = total;
-            if (f.host_summary) {
-                const uint64_t *src = reinterpret_cast<const uint64_t *>(sum);
-                static_assert(sizeof(PlanSummary) % 8 == 0, "summary words");
-                for (uint32_t i = 0; i < sizeof(PlanSummary) / 8; ++i) {
-                    const uint64_t v = i == offsetof(PlanSummary, matches) / 8 ? total : src[i];
-                    __hip_atomic_store(f.host_summary + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
+    extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
+    __shared__ uint32_t sh_pick;
+    __shared__ uint32_t wsum[FJ_WAVES];
+    const uint32_t n = f.ticket[2];                   // written by k_join_fused, which is through
+    if (n == 0 || !f.j.summary->fused_ok || f.j.out == nullptr) return;
+    const bool narrow = f.j.summary->wide_row_ids == 0;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const FjWalkItem it = f.walk[i];
+        const bool res = (it.flags & 1u) != 0;
+        if (it.flags & 2u) {                          // (FjHashT<true> comes with the kernels that may keep build tuples resident)
+            if (narrow) { if (res) fj_walk_unit<true, true, true>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
+                          else     fj_walk_unit<false, true, true>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick); }
+            else        { if (res) fj_walk_unit<true, false, true>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
+                          else     fj_walk_unit<false, false, true>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick); }
+        } else {
+            if (narrow) fj_walk_unit<false, true, false>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
+            else        fj_walk_unit<false, false, false>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
         }
     }
 }

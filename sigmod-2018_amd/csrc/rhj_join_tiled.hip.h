@@ -148,8 +148,11 @@ __global__ __launch_bounds__(1024) void k_small_scan_plan(RelArgs r0, RelArgs r1
     // one scan over both halves: S's digits sit behind R's, so take R's total off again
     uint64_t all;
     const uint64_t ex = block_excl_scan<1024>(tot, &all, sm);
+    __shared__ uint64_t r_kept;                       // R's tuples that take part: all of R, unless the join is sharded by bucket range
+    if (threadIdx.x == 512) r_kept = ex;              // (everything in front of S's first digit)
+    __syncthreads();
     if (t < bins) {
-        const uint64_t e = rel ? ex - r0.n : ex;      // exclusive prefix inside S = prefix over both - all of R
+        const uint64_t e = rel ? ex - r_kept : ex;    // exclusive prefix inside S = prefix over both - R's part
         hist[(size_t)rel * bins + t] = tot;
         psum[(size_t)rel * bins + t] = e;
         base_sh[rel][t] = (uint32_t)e;

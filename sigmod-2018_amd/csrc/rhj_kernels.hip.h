@@ -6,33 +6,33 @@
 //   k_scan_*         hist merge + psum            preprocess.c:83-102 / :328-340
 //   k_scatter_lds    SerialReorderArray scatter   preprocess.c:349-359 (stable)
 //   k_plan           bucket loop / side choice    rhjoin.c:79-102 (>= picks the probe side)
-//   k_build_lds / k_build_hbm   InitIndex + CreateIndex   rhjoin.c:253-273, :219-250
-//   k_probe          GetResults                   rhjoin.c:141-217
+//   k_local_part / k_scatter_runs   the same stable scatter in two LSD passes (radix bits 9..15)
+//   fj_build / k_build_lds / k_build_hbm   InitIndex + CreateIndex   rhjoin.c:253-273, :219-250
+//   k_join_fused / k_join_walk / k_probe   GetResults + MergeResults   rhjoin.c:141-217, :354-392
 //   k_filter_*       Filter                       filter.c:110-183
 //
-// Partition.  A pass handles at most 8 digit bits: a workgroup ranks a 4096-tuple
-// tile stably (wave match-any ballots + per-wave LDS counters), stages it in LDS in
-// digit order and writes every digit run as full 16-byte-per-lane coalesced stores
-// (a direct 4096-way scatter of 16-byte tuples measured 2.6x write amplification and
-// 834 GB/s on MI355X: profiles/r01a).  Wider radixes (9..12 bits) run two stable LSD
-// passes (low half, then high half), which yields the same stable order as one pass.
-//
-// Hash index.  The reference chains bucket positions in DESCENDING order behind a
-// prime-modulus slot (CreateIndex walks last->first and appends at the tail), which
-// is what fixes the order of duplicate matches.  Here each bucket's index is an
-// ORDERED linear-probing table (Amble & Knuth): an entry is (tag | position+1),
-// inserted with atomic max so that along every probe run entries are in descending
-// (tag, position) order.  The final table is the same for every insertion
-// interleaving (deterministic), a walk from a key's home slot meets that key's
-// duplicates in descending position — the reference's chain order — and can stop at
-// the first entry whose tag is smaller.  Tags only pre-filter: every candidate is
-// verified against the build tuple's full 64-bit key, so results are exact.
-// Tables live in HBM (L2-resident while their bucket is being probed):
-//   * 32-bit entries (16-bit tag, 16-bit position), built in LDS by one workgroup per
-//     bucket and dumped, when the bucket's build side has <= lds_cap tuples;
-//   * 64-bit entries (32-bit tag, 32-bit position), built with global atomics, else.
-// Probe units are tiles of 2048 probe tuples in canonical order; any number of
-// workgroups share a bucket's table, so a hot bucket costs no extra build work.
+// The device code by path (one header each; the design notes sit at the top of every header and in DESIGN.md §4):
+//   rhj_partition.hip.h    stable radix partition.  Radix bits <= 8: one pass (k_hist_tiles, k_scan_*, k_scatter_lds: a
+//                          4096-tuple tile ranked by wave match-any ballots + per-wave LDS counters, staged in LDS in digit
+//                          order, written run by run).  Bits 9..15: two LSD passes in RUN FORM — k_local_part partitions every
+//                          tile in place on the low half of the bits (no histogram, no offsets; 12-byte tuples when the row ids
+//                          fit 32 bits), k_hist_runs / k_scan_* give pass 2 its offsets from one byte per tuple, k_scatter_runs
+//                          moves the runs to their final places (software-pipelined, persistent, XCD-aware tile order).
+//   rhj_small.hip.h        joins of up to 4 M tuples per side on <= 8 bits: the partition in two launches, the plan riding along.
+//   rhj_join_fused.hip.h   the default join: one persistent workgroup per CU takes (bucket, <= 65536 probe tuples) units by
+//                          ticket; per unit a CSR slot index of the build side in LDS ((tag16, position) entries sorted
+//                          descending per slot = the reference's chain order), the probe side streamed once with one verifying
+//                          gather per candidate — or none when the build tuples fit LDS too —, match counts chained through a
+//                          decoupled look-back, pairs emitted by a deferred streaming pass; k_join_walk for the rare units
+//                          that pass cannot describe.
+//   rhj_join_tiled.hip.h   buckets beyond the LDS index: ordered linear-probing tag tables in HBM (Amble-Knuth order by
+//                          (tag, position) via atomic max: deterministic, duplicates meet in descending position), count and
+//                          emit passes over 1024-tuple probe tiles.
+//   rhj_subjoin.hip.h      opt-in: partition k bits further than the join's radix, LDS-resident sub-buckets, canonical order
+//                          restored by one byte per tuple (included by rhj_device.hip behind this hub).
+//   rhj_filter.hip.h       predicate -> ballot masks -> ascending index list.
+// Tags only pre-filter everywhere: every candidate is verified against the build tuple's full 64-bit key, so results are exact
+// for any hash and any tag collision.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

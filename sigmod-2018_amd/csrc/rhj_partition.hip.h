@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
 #pragma unroll 4
         for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
             const uint32_t k = (uint32_t)(r.in[i].value >> shift);
+            if (r.range_span && ((k & mask) - r.range_lo) >= r.range_span) continue;   // sharded join: another rank's bucket
             atomicAdd(&tile_h[k & mask], 1u);
         }
         __syncthreads();
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
     for (int k = 0; k < PT_V; ++k) {
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch)
         const uint32_t d = (uint32_t)(key >> shift) & mask;
+        if (r.range_span) ok[k] = ok[k] && (d - r.range_lo) < r.range_span;      // sharded join: another rank's buckets are dropped here
         dig[k] = d;
         const uint64_t peers = digit_peers(d, ok[k], bits);
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
         }
         mytotal = run;
     }
-    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+    uint64_t kept64;                                      // the tile's tuples that stay (all of them unless the join is sharded)
+    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, &kept64, sm);
     if (threadIdx.x < bins) {
         dstart[threadIdx.x] = (uint32_t)ds;
         delta[threadIdx.x] = r.cnt[(size_t)tile * bins + threadIdx.x] - (uint32_t)ds;   // mod 2^32
@@ -231,10 +234,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
     __syncthreads();
 
     uint4 *out = reinterpret_cast<uint4 *>(r.out);
+    const uint32_t kept = (uint32_t)kept64;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t p = k * PT_BLOCK + threadIdx.x;
-        if (p < count) {
+        if (p < kept) {
             const uint4 v = stage[p];
             const uint32_t d = (v.x >> shift) & mask;
             const uint32_t dst = delta[d] + p;
@@ -305,12 +309,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     }
     __syncthreads();
 
+    // sharded join (rhj_join_device_range): only the tuples whose bucket — the low shift + bits + next_bits key bits — lies in
+    // the rank's range go on; the tile shrinks in place, its run table says by how much, and everything downstream reads runs
+    const uint32_t full_mask = (1u << (shift + bits + next_bits)) - 1u;
     uint32_t lrank[PT_V], dig[PT_V];
     uint32_t *mycnt = wcnt + w * bins;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
+        if (r.range_span) ok[k] = ok[k] && (((uint32_t)key & full_mask) - r.range_lo) < r.range_span;
         dig[k] = d;
         uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
         for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
@@ -339,9 +347,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
         }
         mytotal = run;
     }
-    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+    uint64_t kept64;                                      // the tile's tuples that stay (all of them unless the join is sharded)
+    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, &kept64, sm);
+    const uint32_t kept = (uint32_t)kept64;
     if (threadIdx.x < bins) dstart[threadIdx.x] = (uint32_t)ds;
-    if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : count);
+    if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : kept);
     __syncthreads();
 
 #pragma unroll
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t p = k * PT_BLOCK + threadIdx.x;
-        if (p < count) {
+        if (p < kept) {
             const uint4 v = stage[p];
             if (T12) { out12[p] = Tuple12{v.x, v.y, v.z}; wide = wide || v.w != 0; }
             else out[p] = v;
@@ -484,6 +494,233 @@ __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, 
 #endif
 constexpr int SR_V = SR_VN;
 constexpr int SR_TILE = PT_BLOCK * SR_V;
+constexpr uint32_t SR_RUNOFF = PT_MAX_GROUP + 8;  // run-start table of a pass-2 tile: entries behind the last run hold the tile's total
+#ifdef RHJ_INSTRUMENT
+__device__ uint64_t g_sr_dbg[256 * 16];           // diagnostics build: phase stamps (100 MHz) of the first 256 workgroups' FOURTH batch
+#define SR_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256 && iter == 3) g_sr_dbg[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SR_STAMP(slot) do { } while (0)
+#endif
+#ifndef SR_PIPE
+#define SR_PIPE 1       // 1: the next batch's tuple loads are issued before the current batch is written out (0: the round-2 loop, for A/B)
+#endif
+#if SR_PIPE
+// A batch of a pass-2 tile costs a workgroup a chain of dependent steps; in-kernel stamps of the round-2 loop (r03, 10.6 us
+// per batch, two workgroups per CU): ranks 2.4 us, staging 1.2, run table of the next tile 1.3, run search + load issue 1.8,
+// write-out 2.1, barriers 1.5 — with the loads and stores switched off the kernel still took 0.52 of its 0.70 ms per 100 M
+// tuples: the chain, not the bandwidth, sets the pace.  So:
+//   * software pipeline: a batch's tuples are dead in registers once they are staged, so the NEXT batch's loads are issued
+//     right there — before the write-out — and fly behind the write-out, the barriers and the zeroing of the counters; the
+//     next TILE's run table is built in the other half of a double buffer at the same point;
+//   * run search by the wave: lanes 0..7 find the run of their round's first element (one binary search for the wave), a lane's
+//     own run is at most three further on (three independent reads) — it was a chain of ~30 dependent LDS reads per lane;
+//   * 12-byte tuples are staged as three word arrays (the 16-byte slots' scattered stores were 20 % of the kernel's CU cycles
+//     in bank conflicts; a quarter of their bytes was padding);
+//   * the per-wave digit counters are bumped by LDS atomics that return the old value: the rounds no longer wait on each other.
+template <bool T12, bool O12>
+__global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
+                                                           const PlanSummary *summary)
+{
+    if ((summary->wide_row_ids == 0) != T12) return;      // the other instantiation's launch moves the data
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4    *stage = reinterpret_cast<uint4 *>(smem);                        // [SR_TILE] (16-byte tuples)
+    uint32_t *s_klo = reinterpret_cast<uint32_t *>(smem);                      // [SR_TILE] x 3 (12-byte tuples)
+    uint32_t *s_khi = s_klo + SR_TILE, *s_rid = s_khi + SR_TILE;
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)SR_TILE * 16); // [PT_WAVES][bins]
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
+    uint32_t *delta = dstart + bins;                                           // [bins]
+    uint64_t *sm = reinterpret_cast<uint64_t *>(delta + bins);                 // scan scratch [PT_BLOCK / 64 + 1]
+    uint32_t *gbase = reinterpret_cast<uint32_t *>(sm + PT_BLOCK / 64 + 2);    // [bins] next output position per digit
+    uint32_t *runoff0 = gbase + bins;                                          // [2][SR_RUNOFF] first element of run i (double-buffered per tile)
+    uint32_t *rbase0 = runoff0 + 2 * SR_RUNOFF;                                // [2][PT_MAX_GROUP] physical index of element e of run i = rbase[i] + e
+
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in);
+    uint4 *out = reinterpret_cast<uint4 *>(r.out);
+
+    // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx.x % 8), each with its own L2.  Consecutive pass-2 tiles
+    // write ADJACENT pieces of every digit's output, so the cache line at the seam is completed by the neighbour tile: the
+    // tiles are dealt to the XCDs in blocks of as many consecutive tiles as an XCD has workgroups, which walk the block
+    // together — both halves of a seam line meet in the same L2 and leave as one full-line write (-6 % against a plain grid
+    // stride) — and the blocks go round-robin over the XCDs, so that the oversized tiles of a hot digit (Zipf keys) are
+    // shared by all of them (-5 % on 100M x 1B against one contiguous eighth per XCD; same on uniform keys).
+    const uint32_t xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t tstep = 8u * per_xcd;
+    const uint32_t t_end = r.tiles;
+    uint32_t tile2 = xcd * per_xcd + slot;
+    if (tile2 >= t_end) return;
+
+    // run table of a tile: scan of the run lengths the threads hold -> runoff / rbase of buffer `buf` (entries from `group` on
+    // hold the tile's total, also in runoff[PT_MAX_GROUP]); the tile's output positions per digit -> gbase (the previous
+    // tile's last batch has consumed gbase)
+    auto build_runs = [&](uint32_t buf, uint32_t phys, uint32_t len, uint32_t gb) {
+        uint32_t *runoff = runoff0 + buf * SR_RUNOFF, *rbase = rbase0 + buf * PT_MAX_GROUP;
+        uint64_t tot64;
+        const uint32_t off = (uint32_t)block_excl_scan<PT_BLOCK>(len, &tot64, sm);
+        if (threadIdx.x < SR_RUNOFF) runoff[threadIdx.x] = threadIdx.x < r.group ? off : (uint32_t)tot64;
+        if (threadIdx.x < PT_MAX_GROUP) rbase[threadIdx.x] = phys - off;
+        if (threadIdx.x < bins) gbase[threadIdx.x] = gb;
+        return (uint32_t)tot64;
+    };
+    uint32_t tk[SR_V], th[SR_V], tr[SR_V], tw[SR_V];  // the batch's tuples (tw: upper row-id word of 16-byte tuples)
+    // run search + loads of batch [sb, sb + count) of the tile whose run table is in buffer `buf`
+    auto issue_loads = [&](uint32_t buf, uint32_t sb, uint32_t count) {
+        const uint32_t *runoff = runoff0 + buf * SR_RUNOFF, *rbase = rbase0 + buf * PT_MAX_GROUP;
+        // lanes 0..7: the last run that starts at or before the first element of this wave's round `lane`
+        uint32_t pos = 0;
+        {
+            const uint32_t e0 = sb + w * (WAVE * SR_V) + (lane & 7u) * WAVE;
+            for (uint32_t s2 = search0; s2 >= 1; s2 >>= 1)
+                if (runoff[pos + s2] <= e0) pos += s2;
+        }
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            const uint32_t i = w * (WAVE * SR_V) + k * WAVE + lane;
+            const uint32_t e = sb + i;
+            const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
+            const uint32_t a1 = runoff[j0 + 1], a2 = runoff[j0 + 2], a3 = runoff[j0 + 3], a4 = runoff[j0 + 4];   // (wave-uniform addresses)
+            uint32_t j = j0 + (a1 <= e ? 1u : 0u) + (a2 <= e ? 1u : 0u) + (a3 <= e ? 1u : 0u);
+            if (a4 <= sb + w * (WAVE * SR_V) + (uint32_t)k * WAVE + (WAVE - 1)) {            // short or empty runs: more than four runs under these 64 elements (wave-uniform)
+                j = j0;
+                while (runoff[j + 1] <= e && j + 1 < r.group) ++j;
+            }
+            tk[k] = th[k] = tr[k] = tw[k] = 0;
+            if (i < count) {
+                if (T12) { const Tuple12 x = reinterpret_cast<const Tuple12 *>(r.in)[rbase[j] + e]; tk[k] = x.klo; th[k] = x.khi; tr[k] = x.rid; }
+                else { const uint4 x = in[rbase[j] + e]; tk[k] = x.x; th[k] = x.y; tr[k] = x.z; tw[k] = x.w; }
+            }
+        }
+    };
+
+    uint32_t nphys = 0, nlen = 0, ngb = 0;            // the NEXT tile's run (thread i: run i) and output positions, prefetched
+    pt_run_of(r, tile2, threadIdx.x, nphys, nlen);
+    if (threadIdx.x < bins) ngb = r.cnt[(size_t)tile2 * bins + threadIdx.x];
+    uint32_t buf = 0;
+    uint32_t total = build_runs(buf, nphys, nlen, ngb);
+    {
+        const uint32_t nt = tile2 + tstep;
+        nphys = 0; nlen = 0;
+        if (nt < t_end) {
+            pt_run_of(r, nt, threadIdx.x, nphys, nlen);
+            if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+    __syncthreads();
+    uint32_t sb = 0;
+    uint32_t count = min((uint32_t)SR_TILE, total);
+    issue_loads(buf, sb, count);
+    bool more = true;
+    for (uint32_t iter = 0; more; ++iter) {
+        (void)iter;                                   // (stamps of the diagnostics build)
+        SR_STAMP(0);
+        __syncthreads();                              // counters are zero, run tables visible
+        SR_STAMP(1);
+#ifdef RHJ_INSTRUMENT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostics: how long the batch's loads are still out at this point
+        SR_STAMP(10);
+#endif
+        uint32_t rk[SR_V];                            // rank among the wave's tuples of the digit so far | digit << 16
+        uint32_t *mycnt = wcnt + w * bins;
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            const bool ok = w * (WAVE * SR_V) + k * WAVE + lane < count;
+            const uint64_t key = ((uint64_t)th[k] << 32) | tk[k];
+            const uint32_t d = (uint32_t)(key >> shift) & mask;
+            const uint64_t peers = digit_peers(d, ok, bits);
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            uint32_t old = 0;
+            if (ok && rank == 0) old = atomicAdd(&mycnt[d], (uint32_t)__popcll(peers));   // lowest lane of each digit group (one lane per
+            const int leader = ok ? __ffsll((unsigned long long)peers) - 1 : 0;           // counter: no ordering between lanes is relied on)
+            old = __shfl(old, leader, 64);
+            rk[k] = (old + rank) | (d << 16);
+        }
+        SR_STAMP(2);
+        __syncthreads();
+        SR_STAMP(3);
+
+        uint64_t mytotal = 0;
+        if (threadIdx.x < bins) {
+            uint32_t run = 0;
+            for (int ww = 0; ww < PT_WAVES; ++ww) {
+                const uint32_t c = wcnt[ww * bins + threadIdx.x];
+                wcnt[ww * bins + threadIdx.x] = run;
+                run += c;
+            }
+            mytotal = run;
+        }
+        const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+        if (threadIdx.x < bins) {
+            dstart[threadIdx.x] = (uint32_t)ds;
+            const uint32_t gb = gbase[threadIdx.x];
+            delta[threadIdx.x] = gb - (uint32_t)ds;                 // mod 2^32
+            gbase[threadIdx.x] = gb + (uint32_t)mytotal;
+        }
+        __syncthreads();
+        SR_STAMP(4);
+
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            if (w * (WAVE * SR_V) + k * WAVE + lane < count) {
+                const uint32_t d = rk[k] >> 16;
+                const uint32_t p = dstart[d] + mycnt[d] + (rk[k] & 0xffffu);
+                if (T12) { s_klo[p] = tk[k]; s_khi[p] = th[k]; s_rid[p] = tr[k]; }
+                else stage[p] = make_uint4(tk[k], th[k], tr[k], tw[k]);
+            }
+        }
+
+        SR_STAMP(5);
+        // ---- the next batch: same tile, or the next tile (its run table goes to the other buffer)
+        const uint32_t wcount = count;                // the batch being written out
+        uint32_t nsb = sb + SR_TILE;
+        bool next_tile = false;
+        if (nsb >= total) {
+            nsb = 0;
+            tile2 += tstep;
+            more = tile2 < t_end;
+            next_tile = more;
+        }
+        if (next_tile) {                              // (workgroup-uniform)
+            buf ^= 1u;
+            total = build_runs(buf, nphys, nlen, ngb);
+            const uint32_t nt = tile2 + tstep;
+            nphys = 0; nlen = 0;
+            if (nt < t_end) {
+                pt_run_of(r, nt, threadIdx.x, nphys, nlen);
+                if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+            }
+        }
+        SR_STAMP(6);
+        __syncthreads();                              // staged tile, run table and gbase are visible
+        SR_STAMP(7);
+        sb = nsb;
+        if (more) {
+            count = min((uint32_t)SR_TILE, total - sb);
+            issue_loads(buf, sb, count);              // in flight during the write-out below
+        }
+        SR_STAMP(8);
+
+#pragma unroll
+        for (int k = 0; k < SR_V; ++k) {
+            const uint32_t p = k * PT_BLOCK + threadIdx.x;
+            if (p < wcount) {
+                uint4 v;
+                if (T12) v = make_uint4(s_klo[p], s_khi[p], s_rid[p], 0u);
+                else v = stage[p];
+                const uint32_t d = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> shift) & mask;
+                if (O12) reinterpret_cast<Tuple12 *>(r.out)[delta[d] + p] = Tuple12{v.x, v.y, v.z};
+                else out[delta[d] + p] = v;
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
+        SR_STAMP(9);
+    }
+}
+#else
 template <bool T12, bool O12>
 __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
                                                            const PlanSummary *summary)
@@ -633,5 +870,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
     }
     }   // grid-stride loop
 }
+
+#endif
 
 }  // namespace rhj

@@ -8,10 +8,10 @@ a single join:
   predicates that share no relation, inter_res.c:147-150) are dealt to ranks, largest first
   (`assign_joins`, `run_independent_joins`); each rank runs whole joins on its own GPU;
 * inside one join — bucket b of R only ever meets bucket b of S (rhjoin.c:42-57), so ranks
-  take contiguous BUCKET RANGES balanced by histR+histS (`bucket_ranges`), select their
-  tuples with a stable device-side compaction, join them through `rhj_join_device`
-  (`sharded_join`), and the concatenation of the per-rank pair lists in rank order IS the
-  canonical order.
+  take contiguous BUCKET RANGES (equal width, or balanced by histR+histS: `bucket_ranges`) and
+  join them with ONE call each — `rhj_join_device_range`: the join's own first partition pass
+  drops the other ranks' buckets while it reads the relations — (`sharded_join`), and the
+  concatenation of the per-rank pair lists in rank order IS the canonical order.
 
 The one exchange step is the match-list all-gather-v, issued only when the consumer of a
 join's result lives on another GPU (`allgatherv_pairs`): an 8-byte count all-gather, then
@@ -90,13 +90,22 @@ class RhjOps:
                                % (rc, got.value, int(count)))
         return out[:int(count)]
 
-    def join(self, R, S, bits):
+    def join(self, R, S, bits, bucket_range=None):
+        """the canonical pair list of R x S — of the buckets [lo, hi) only when a range is given (rhj_join_device_range: the
+        join's own first partition pass drops the other buckets; no selection pass, one read of each relation)"""
         self.rhj.set_bits(bits)
-        if R.shape[0] == 0 or S.shape[0] == 0:
+        if R.shape[0] == 0 or S.shape[0] == 0 or (bucket_range is not None and bucket_range[0] >= bucket_range[1]):
             return self.torch.empty((0, 2), dtype=self.torch.int64, device=R.device)
-        pairs, m = self.rhj.join_device(R, S, capacity=max(int(S.shape[0]), int(R.shape[0])))
+        if self.rhj.lib.rhj_get_order():
+            # the concatenation of the ranks' lists is the canonical order of THIS radix: with the order left to the library
+            # every rank would pick its own radix from its slice sizes
+            raise RuntimeError("sharded joins need the canonical order mode (rhj_set_order(0) / RHJ_ORDER unset)")
+        guess = max(int(S.shape[0]), int(R.shape[0]))
+        if bucket_range is not None:
+            guess = max(guess * (bucket_range[1] - bucket_range[0]) // (1 << bits) * 5 // 4, 1 << 16)
+        pairs, m = self.rhj.join_device(R, S, capacity=guess, bucket_range=bucket_range)
         if m > pairs.shape[0]:                      # fan-out above the guess: the count is known now
-            pairs, m = self.rhj.join_device(R, S, capacity=m)
+            pairs, m = self.rhj.join_device(R, S, capacity=m, bucket_range=bucket_range)
         return pairs
 
 
@@ -135,26 +144,34 @@ def allgatherv_pairs(local, group=None):
 
 # ------------------------------------------------------------------ one join over all ranks
 
-def sharded_join(ops, R, S, bits, group=None, gather=True):
+def equal_ranges(bits, world):
+    """contiguous bucket ranges of equal width: no histogram, no read-back (uniform keys: balanced to within a bucket)"""
+    bins = 1 << bits
+    cuts = [bins * r // world for r in range(world + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+def sharded_join(ops, R, S, bits, group=None, gather=True, balance="equal"):
     """One RadixHashJoin over the ranks of `group`.  R, S: the whole relations, replicated on every rank
-    (device-resident column store per GPU).  Every rank histograms both relations, takes its bucket range,
-    selects and joins it; with `gather` the pair lists are exchanged so that every rank holds the canonical
-    result.  Returns (pairs, info): pairs = canonical result (gather) or this rank's slice of it."""
+    (device-resident column store per GPU).  Every rank takes a contiguous bucket range and joins it with ONE call
+    (`ops.join(..., bucket_range)`: the join's first partition pass drops the other ranks' buckets while it reads the
+    relations — one read of each relation per rank, nothing in front of the join); with `gather` the pair lists are
+    exchanged so that every rank holds the canonical result.
+    balance = "equal": ranges of equal width, no histogram, no host round trip (the default: at one rank the call IS the
+    plain join); "hist": ranges balanced by histR + histS (skewed keys) — two histogram launches and a 2^bits-word
+    read-back in front of the join.
+    Returns (pairs, info): pairs = canonical result (gather) or this rank's slice of it."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    hr = ops.histogram(R, bits)
-    hs = ops.histogram(S, bits)
-    hr_h, hs_h = hr.cpu().numpy(), hs.cpu().numpy()
-    ranges = bucket_ranges(hr_h, hs_h, world)
-    lo, hi = ranges[rank]
-    cr, cs = int(hr_h[lo:hi].sum()), int(hs_h[lo:hi].sum())
-    if world == 1:
-        Rm, Sm = R, S                               # the whole radix: nothing to select
+    if balance == "hist" and world > 1:
+        hr_h, hs_h = ops.histogram(R, bits).cpu().numpy(), ops.histogram(S, bits).cpu().numpy()
+        ranges = bucket_ranges(hr_h, hs_h, world)
     else:
-        Rm, Sm = ops.select(R, bits, lo, hi, cr), ops.select(S, bits, lo, hi, cs)
-    local = ops.join(Rm, Sm, bits)
-    info = {"range": (lo, hi), "ranges": ranges, "tuples": (cr, cs), "local_pairs": int(local.shape[0])}
+        ranges = equal_ranges(bits, world)
+    lo, hi = ranges[rank]
+    local = ops.join(R, S, bits, None if world == 1 else (lo, hi))
+    info = {"range": (lo, hi), "ranges": ranges, "local_pairs": int(local.shape[0])}
     if not gather or not dist.is_initialized():
         info["counts"] = [int(local.shape[0])]
         return local, info
@@ -165,12 +182,17 @@ def sharded_join(ops, R, S, bits, group=None, gather=True):
 
 # ------------------------------------------------------------------ independent joins of a plan
 
-def run_independent_joins(ops, joins, bits, group=None, gather=True):
+def run_independent_joins(ops, joins, bits, group=None, gather=True, consumers=None):
     """joins: list of (R, S) relation pairs that share no intermediate result (each would start an
     inter_res node of its own, inter_res.c:147-150).  They are dealt to the ranks largest first
-    (`assign_joins`), every rank runs its joins whole, and with `gather` every match list is sent to all
-    ranks (all-gather-v per join: only the owner contributes pairs).  Returns (results, owner):
-    results[i] = pairs of join i (None on ranks that neither own it nor gathered)."""
+    (`assign_joins`) and every rank runs its joins whole.  A match list crosses xGMI only when the
+    operator that consumes it lives on another GPU:
+      consumers[i] = rank that consumes join i's result (it alone receives the list: one send from the owner),
+                     None / -1 = nobody else needs it, "all" = every rank (all-gather-v);
+      consumers = None: gather=True means "all" for every join, gather=False means no exchange.
+    The match counts of ALL joins go through one all-gather (one collective, one host read-back), the lists through
+    one grouped round of isend / irecv.  Returns (results, owner): results[i] = pairs of join i on the ranks that own
+    or consume it, None elsewhere."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -180,8 +202,41 @@ def run_independent_joins(ops, joins, bits, group=None, gather=True):
     for i, (R, S) in enumerate(joins):
         if owner[i] == rank:
             results[i] = ops.join(R, S, bits)
-    if gather and dist.is_initialized() and world > 1:
-        for i, (R, S) in enumerate(joins):
-            mine = results[i] if owner[i] == rank else torch.empty((0, 2), dtype=torch.int64, device=R.device)
-            results[i], _ = allgatherv_pairs(mine, group)
+    if consumers is None:
+        consumers = ["all" if gather else None] * len(joins)
+    if not dist.is_initialized() or world == 1 or not joins:
+        return results, owner
+    wanted = [c for c in consumers if c == "all" or (c is not None and c >= 0)]
+    if not wanted:
+        return results, owner
+    dev = joins[0][0].device
+    # one count exchange for all joins: every rank fills in the joins it owns
+    mine = torch.zeros(len(joins), dtype=torch.int64, device=dev)
+    for i in range(len(joins)):
+        if owner[i] == rank:
+            mine[i] = results[i].shape[0]
+    counts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    total = torch.stack(counts).sum(dim=0).cpu().tolist()              # the one host read-back
+    ops_list = []
+    for i, (R, S) in enumerate(joins):
+        c = consumers[i]
+        if c is None or (c != "all" and c < 0):
+            continue
+        receivers = [r for r in range(world) if r != owner[i]] if c == "all" else ([c] if c != owner[i] else [])
+        n = int(total[i])
+        if rank in receivers:
+            results[i] = torch.empty((n, 2), dtype=torch.int64, device=dev)
+        if n == 0:
+            continue
+        for peer in receivers:
+            gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+            gown = dist.get_global_rank(group, owner[i]) if group is not None else owner[i]
+            if rank == owner[i]:
+                ops_list.append(dist.P2POp(dist.isend, results[i].contiguous(), gpeer, group))
+            elif rank == peer:
+                ops_list.append(dist.P2POp(dist.irecv, results[i], gown, group))
+    if ops_list:
+        for req in dist.batch_isend_irecv(ops_list):
+            req.wait()
     return results, owner

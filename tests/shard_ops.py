@@ -1,5 +1,5 @@
 """Stand-in for sigmod-2018_amd.shard.RhjOps where no GPU exists (CPU gloo tests): the same three device
-steps — bucket histogram, stable bucket-range selection, join — restated with numpy and the oracle on
+steps — bucket histogram, stable bucket-range selection, (ranged) join — restated with numpy and the oracle on
 CPU tensors.  Test infrastructure only; the product's sharding code (shard.py) is what runs around it."""
 import numpy as np
 import torch
@@ -24,8 +24,14 @@ class OracleOps:
         assert out.shape[0] == count
         return out
 
-    def join(self, R, S, bits):
+    def join(self, R, S, bits, bucket_range=None):
+        """bucket_range = (lo, hi): the canonical result restricted to those buckets — what rhj_join_device_range returns:
+        here the oracle's join of the stable selections (bucket b of R only meets bucket b of S, rhjoin.c:42-57)"""
         self.calls["join"] += 1
+        if bucket_range is not None:
+            lo, hi = bucket_range
+            bR, bS = R[:, 0] & ((1 << bits) - 1), S[:, 0] & ((1 << bits) - 1)
+            R, S = R[(bR >= lo) & (bR < hi)], S[(bS >= lo) & (bS < hi)]
         ra = np.ascontiguousarray(R.numpy()).view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
         rb = np.ascontiguousarray(S.numpy()).view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
         if len(ra) == 0 or len(rb) == 0:

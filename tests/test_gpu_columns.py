@@ -63,10 +63,11 @@ def test_registered_map_is_the_only_cache(rhj, mod, oracle):
     rm[0].num_tuples, rm[0].num_columns = n, 3
     rm[0].columns = C.cast(ptrs, C.POINTER(C.c_void_p))
     base_cols, base_pins = lib.rhj_registered_columns(), lib.rhj_pinned_ranges()
+    base_refused = lib.rhj_pin_refusals()
     assert lib.rhj_register_relation_map(rm, 1) == 0
     assert lib.rhj_registered_columns() == base_cols + 3
-    pinned = lib.rhj_pinned_ranges() - base_pins
-    assert pinned in (0, 1), "one hipHostRegister for the relation's contiguous block (0 if the host refuses to pin)"
+    # numpy's malloc'd memory IS pinnable: exactly one hipHostRegister for the relation's contiguous block, none refused
+    assert lib.rhj_pinned_ranges() == base_pins + 1 and lib.rhj_pin_refusals() == base_refused
     want = [oracle.filter(c.copy(), ">", 400) for c in cols]
     for c in range(3):
         assert np.array_equal(rhj.Filter(cols, n, c, ">", 400), want[c])

@@ -48,17 +48,22 @@ def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode, engine
 
 
 def test_bench_small_workload_mode_checks_and_reports(tmp_path):
-    """bench.py --workload small (BASELINE configs[4], query-sharded): the run itself asserts that the merged
-    answers equal small.result; here one rank, one step."""
+    """bench.py --workload small (BASELINE configs[4], query-sharded): ONE engine process per rank stays alive, a step is a
+    batch of the rank's queries and only batch submission -> last answer is timed (start-up is reported beside it); the run
+    itself asserts that the merged answers equal small.result.  Here one rank, three timed batches."""
     import json
     import sys
     if not os.path.exists(ENGINES["radixhash_rhj_resident"]):
         pytest.skip("oracle/_ref/radixhash_rhj_resident not built")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "1", "--warmup", "0",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "3", "--warmup", "1",
                           "--no-cpu-baseline"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     line = json.loads(res.stdout.decode().strip().splitlines()[-1])
     assert line["config"]["answers"] == "identical to small.result" and line["config"]["queries"] == 50 and line["value"] > 0
+    # query work, not process start-up: a batch of the 50 queries takes tens of milliseconds, HIP start-up alone 0.1-0.3 s
+    assert line["ms_per_step"] < 150.0, line
+    assert line["config"]["startup_s"] > line["ms_per_step"] / 1e3, line
+    assert "round-robin" in line["config"]["parallelism"]
 
 
 @pytest.mark.parametrize("bits", ["4", "10"])

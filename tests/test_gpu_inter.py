@@ -397,7 +397,15 @@ def test_init_relation_map_matches_the_reference(mod, rhj, golden, tmp_path):
             nodes[k].next = C.pointer(nodes[k + 1]) if k + 1 < len(files) else None
         rm = (mod.RelationMap * len(files))()
         lib.InitRelationMap.argtypes = [C.POINTER(ListNode), C.POINTER(mod.RelationMap)]
+        if lib is rhj.lib:
+            pins, refused = lib.rhj_pinned_ranges(), lib.rhj_pin_refusals()
         lib.InitRelationMap(nodes, rm)
+        if lib is rhj.lib:
+            # every relation's column block above 64 KiB is a read-only file mapping (PROT_READ | MAP_PRIVATE) that the
+            # library pins for the upload: the host must have taken all of them (RHJ_TRACE=1 prints the flag it accepted)
+            big = sum(1 for r in range(len(files)) if golden.small_relations["r%d" % r].size * 8 >= 64 << 10)
+            assert lib.rhj_pinned_ranges() - pins == big and lib.rhj_pin_refusals() == refused, (
+                "file mappings pinned %d of %d, refused %d" % (lib.rhj_pinned_ranges() - pins, big, lib.rhj_pin_refusals() - refused))
         stats = []
         for r in range(len(files)):
             assert rm[r].num_tuples == golden.small_relations["r%d" % r].shape[1]

@@ -1,5 +1,5 @@
 """GPU: the sharded join (sigmod-2018_amd/shard.py) with its device steps on the MI355X — RhjOps =
-rhj_bucket_histogram_device, rhj_select_bucket_range_device, rhj_join_device of librhj.so — and the
+rhj_join_device_range (and rhj_bucket_histogram_device, rhj_select_bucket_range_device, rhj_join_device) of librhj.so — and the
 exchange step over RCCL (backend "nccl"), at the world size this box offers (1 GPU under gpurun), checked
 bit for bit against the oracle.  The rank-count-dependent part (who takes which range, exact-size
 all-gather-v between peers) is covered at world_size 2 on gloo in tests/test_shard_gloo.py; here every
@@ -62,10 +62,11 @@ def test_sharded_join_on_the_device_under_nccl(rhj, shard, oracle, nccl_world, k
     R, S = relations(oracle, kind)
     dR, dS = rhj.to_device(R), rhj.to_device(S)
     want = oracle.join(R, S, bits)
-    # the whole path at this box's world size: histogram, ranges, join, all-gather-v over RCCL
-    full, info = shard.sharded_join(ops, dR, dS, bits)
-    assert info["ranges"] == [(0, 1 << bits)] and info["counts"] == [len(want)]
-    assert np.array_equal(rhj.pairs_to_numpy(full), want)
+    # the whole path at this box's world size: ranges, (ranged) join, all-gather-v over RCCL
+    for balance in ("equal", "hist"):
+        full, info = shard.sharded_join(ops, dR, dS, bits, balance=balance)
+        assert info["ranges"] == [(0, 1 << bits)] and info["counts"] == [len(want)]
+        assert np.array_equal(rhj.pairs_to_numpy(full), want)
     # histogram against numpy
     mask = np.uint64((1 << bits) - 1)
     hr = np.bincount((R["value"] & mask).astype(np.int64), minlength=1 << bits)
@@ -83,6 +84,17 @@ def test_sharded_join_on_the_device_under_nccl(rhj, shard, oracle, nccl_world, k
             assert np.array_equal(got[:, 0], R["value"][sel]) and np.array_equal(got[:, 1], R["row_id"][sel])
             parts.append(rhj.pairs_to_numpy(ops.join(Rm, Sm, bits)))
         assert np.array_equal(np.concatenate(parts), want), (world, bits, kind)
+    # the same ranges through ONE call each — rhj_join_device_range: the join's first partition pass drops the other ranks'
+    # buckets — equal-width and histogram-balanced splits; concatenation = canonical order, every slice = the oracle's slice
+    keyR = {int(r): int(v) for r, v in zip(R["row_id"], R["value"])} if len(R) < 100000 else None
+    for world in (2, 3, 8):
+        for ranges in (shard.equal_ranges(bits, world), shard.bucket_ranges(hr, hs, world)):
+            parts = [rhj.pairs_to_numpy(ops.join(dR, dS, bits, rng)) for rng in ranges]
+            assert np.array_equal(np.concatenate(parts), want), (world, bits, kind, ranges)
+            if keyR is not None:                   # every slice holds exactly its own buckets
+                for (lo, hi), part in zip(ranges, parts):
+                    b = np.array([keyR[int(x)] for x in part["row_idR"][:2000]], dtype=np.uint64) & mask
+                    assert ((b >= lo) & (b < hi)).all()
 
 
 def test_allgatherv_and_independent_joins_on_device_tensors(rhj, shard, oracle, nccl_world):

@@ -107,3 +107,16 @@ def test_order_mode_and_its_radix_rule(lib):
     for n in (3, 1000, 77_777, 5_000_000, 300_000_000):
         for m in (n, 5 * n):
             assert 1 <= rule(n, m) <= 15 and rule(n, m) == rule(m, n)
+
+
+@pytest.mark.parametrize("target", ["asan", "tsan"])
+def test_host_side_is_clean_under_the_sanitizers(target):
+    """`make asan` / `make tsan` (sigmod-2018_amd/Makefile): rhj_abi.c (result lists, node pool, RadixHashJoin()'s list
+    assembly) and rhj_host.cpp (API lock, the ring-of-staging-blocks mover threads) built with -fsanitize=address,undefined /
+    thread and driven by tests/host_san_driver.cpp — the device replaced by a host stand-in, the reference entry points called
+    from four threads at once.  A sanitizer report ends the driver with a non-zero exit code."""
+    import subprocess
+    res = subprocess.run(["make", "-C", os.path.join(ROOT, "sigmod-2018_amd"), target], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = res.stdout.decode()
+    assert res.returncode == 0 and "host_san_driver ok" in out, out[-3000:]
+    assert "Sanitizer" not in out and "runtime error" not in out, out[-3000:]

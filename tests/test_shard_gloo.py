@@ -48,12 +48,15 @@ def _worker(rank, world, port, bits, out_q):
     def as_pairs(t):
         return t.numpy().view(np.uint64).reshape(-1, 2).copy().view(PAIR).reshape(-1)
 
-    # (1) one join sharded by bucket range, pair lists exchanged
+    # (1) one join sharded by bucket range — ONE ranged join call per rank, nothing in front of it — pair lists exchanged
     full, info = shard.sharded_join(ops, tR, tS, bits)
     want = o.join(R, S, bits)
     got = as_pairs(full)
     ok1 = len(got) == len(want) and bool((got == want).all()) and sum(info["counts"]) == len(want)
-    ok1 = ok1 and ops.calls == {"histogram": 2, "select": 2, "join": 1}
+    ok1 = ok1 and ops.calls == {"histogram": 0, "select": 0, "join": 1}
+    # (1b) ranges balanced by histR + histS (Zipf keys): two histograms in front, same canonical result
+    fullh, infoh = shard.sharded_join(ops, tR, tS, bits, balance="hist")
+    ok1 = ok1 and bool((as_pairs(fullh) == want).all()) and ops.calls == {"histogram": 2, "select": 0, "join": 2}
     # (2) kept sharded (the consumer lives on this rank): this rank's slice only
     local, info2 = shard.sharded_join(ops, tR, tS, bits, gather=False)
     off = sum(info["counts"][:rank])
@@ -64,6 +67,15 @@ def _worker(rank, world, port, bits, out_q):
     res, owner = shard.run_independent_joins(ops, tj, bits)
     ok3 = all(bool((as_pairs(r) == o.join(a, b, bits)).all()) for r, (a, b) in zip(res, rels))
     ok3 = ok3 and owner[0] != owner[2] and len(set(owner)) == 2
+    # (3b) a match list crosses only to the rank that consumes it: join 0 -> the other rank, join 1 -> nobody, join 2 -> its owner
+    cons = [1 - owner[0], None, owner[2]]
+    res_c, owner_c = shard.run_independent_joins(ops, tj, bits, consumers=cons)
+    for i, (a, b) in enumerate(rels):
+        holds = rank == owner_c[i] or (cons[i] is not None and rank == cons[i])
+        if holds:
+            ok3 = ok3 and res_c[i] is not None and bool((as_pairs(res_c[i]) == o.join(a, b, bits)).all())
+        else:
+            ok3 = ok3 and res_c[i] is None
     # (4) the recorded joins of `small` (a subset: the oracle is the device here) dealt to the two ranks
     import helpers
     g = helpers.Golden()
