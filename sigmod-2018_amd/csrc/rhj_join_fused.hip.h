@@ -38,6 +38,8 @@ constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
 constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
 constexpr uint32_t FJ_GROUPS = FJ_SPAN / 256;   // a group = the 256 tuples one wave counts in one batch
+constexpr uint32_t FJ_PATCH_CAP = 128;          // irregular tuples per unit whose match rounds are noted in the overflow buffer's tail
+constexpr uint32_t FJ_OVF_ENT = FJ_OVF_CAP - FJ_PATCH_CAP / 2;   // overflow entries a unit may use (the tail holds the patch words)
 constexpr uint64_t FJ_NO_TOTAL = ~0ull;         // PlanSummary::matches when the last unit's inclusive prefix was never published
 
 struct FusedArgs {
@@ -433,8 +435,10 @@ struct FjGather {
 // finds its (r+1)-th match exactly there) takes a contiguous run of slots with one LDS atomic, records
 // the run's start for (its 256-tuple group, r) and stores the row ids in (k, lane) order.  The emit
 // pass recomputes the same ranks from the stashed counts, so it needs neither the index nor a gather
-// and can run any time later.  Tuples that break the rule (a tag hit with a foreign key next to two or
-// more matches, more than 16 matches, capacity) make the unit fall back to the index walk.
+// and can run any time later.  A tuple that breaks the rule because a tag hit of a FOREIGN key sits between its matches (a
+// 16-bit tag collision inside one slot: ~300 of C3's 100 M probe tuples, but in 7 % of its units) leaves the rounds its
+// matches were found in as a 16-bit map in the unit's patch list, from which the emit pass recomputes exactly what phase 1
+// stored; more than 16 matches of one tuple, a full overflow buffer or patch list send the unit to k_join_walk.
 struct FjOvf {
     uint64_t *buf;        // this unit's overflow entries
     uint32_t *table;      // this unit's [group][16] run starts
@@ -446,13 +450,13 @@ template <bool RES, bool OVF, bool N32, class IX>
 __device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> &G, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
                                                uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
-                                               const FjOvf &O)
+                                               uint32_t (&bm)[FJ_V], const FjOvf &O)
 {
     uint32_t sn[FJ_V], tm[FJ_V];
 #pragma unroll
     for (int k = 0; k < FJ_V; ++k) {
         fj_lookup(X, ((uint64_t)q[k].y << 32) | q[k].x, okk[k], sn[k], tm[k]);
-        c[k] = 0; flo[k] = 0; fhi[k] = 0; fp[k] = false;
+        c[k] = 0; flo[k] = 0; fhi[k] = 0; fp[k] = false; bm[k] = 0;
     }
     bool last = false;
     for (uint32_t round = 0; !last; ++round) {
@@ -475,6 +479,7 @@ __device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> 
             if (eq && c[k] == 0) { flo[k] = g[k].z; fhi[k] = g[k].w; }
             ex[k] = OVF && eq && c[k] != 0;
             c[k] += eq;
+            if (OVF && eq) bm[k] |= 1u << min(round, 31u);        // the rounds this tuple's matches were found in
             fp[k] = fp[k] || (pos[k] != 0xffffffffu && !eq);      // a tag hit with a different key
         }
         if (OVF && round != 0) {
@@ -495,7 +500,7 @@ __device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> 
 #pragma unroll
                 for (int k = 0; k < FJ_V; ++k) {
                     const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
-                    if (ex[k] && slot < FJ_OVF_CAP) reinterpret_cast<uint2 *>(O.buf)[slot] = make_uint2(g[k].z, g[k].w);
+                    if (ex[k] && slot < FJ_OVF_ENT) reinterpret_cast<uint2 *>(O.buf)[slot] = make_uint2(g[k].z, g[k].w);
                     pre += (uint32_t)__popcll(mk[k]);
                 }
             }
@@ -647,8 +652,9 @@ template <bool N32> __device__ __forceinline__ void fj_stash_put(uint2 *srow, ui
 // zero or one match (the foreign-key case), offsets come from ballots.
 template <bool DUP, bool N32>
 __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, uint64_t base, uint32_t *wsum,
-                                               const uint64_t *ovf, uint32_t *table, uint32_t *grab)
+                                               const uint64_t *ovf, uint32_t *table, uint32_t *grab, uint32_t npatch)
 {
+    const uint32_t *patch = reinterpret_cast<const uint32_t *>(ovf + FJ_OVF_ENT);   // (tuple index << 16 | match rounds) of the unit's irregular tuples
     constexpr int V = FJ_V;                           // a wave's step is one 256-tuple group of phase 1
     const JoinArgs &a = f.j;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -686,16 +692,31 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
         if (lane == 0) g = atomicAdd(grab, 1u);
         g = __builtin_amdgcn_readfirstlane(g);
         if (g >= ngroups) break;
-        uint32_t c[V];
+        uint32_t c[V], B[V];                          // matches; the rounds they were found in (bit r: round r)
         uint2 first[V], prow[V];
+        bool irr = false;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const uint32_t i = g * 256u + k * WAVE + lane;
             const bool ok = i < un.count;
-            c[k] = ok ? (scnt[i] & 0x7fu) : 0;
+            const uint32_t sb = ok ? scnt[i] : 0u;
+            c[k] = sb & 0x7fu;
+            B[k] = (1u << min(c[k], 31u)) - 1u;       // the rule: every tag hit a match, the (r + 1)-th match found in round r
+            if (DUP && (sb & 0x80u) && c[k] >= 2u) { irr = true; B[k] = 0x80000000u | i; }
             first[k] = ok ? srow[i] : make_uint2(0, 0);
             if (N32) { prow[k] = make_uint2(first[k].y, 0u); first[k].y = 0u; }
             else     prow[k] = ok ? pr2[2 * (size_t)i + 1] : make_uint2(0, 0);
+        }
+        if (DUP && npatch != 0 && __ballot(irr) != 0) {   // rare: a foreign key's tag hit between a tuple's matches — its rounds are on the patch list
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                if (B[k] & 0x80000000u) {
+                    const uint32_t i = B[k] & 0xffffu;
+                    uint32_t rounds = 0;
+                    for (uint32_t e = 0; e < npatch; ++e) { const uint32_t w32 = patch[e]; if ((w32 >> 16) == i) rounds = w32 & 0xffffu; }
+                    B[k] = rounds;
+                }
+            }
         }
         // the group's table row: lane 0 its start in the unit's output, lane j the run start of ordinal j
         uint32_t tbl_v = 0;
@@ -730,25 +751,33 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
                     const uint32_t j = j0 + jj;
                     uint64_t mk[V];
                     uint32_t tot = 0;
+                    bool later = false;
 #pragma unroll
-                    for (int k = 0; k < V; ++k) { mk[k] = __ballot(c[k] > j); tot += (uint32_t)__popcll(mk[k]); }
-                    any = any || tot != 0;
+                    for (int k = 0; k < V; ++k) {
+                        // round j left an overflow entry of this tuple: a match found there that is not the tuple's first
+                        mk[k] = __ballot(((B[k] >> j) & 1u) != 0 && (B[k] & ((1u << j) - 1u)) != 0);
+                        tot += (uint32_t)__popcll(mk[k]);
+                        later = later || (B[k] >> j) > 1u;
+                    }
+                    any = any || tot != 0 || __ballot(later) != 0;
                     uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, (int)(j & 15u));
 #pragma unroll
                     for (int k = 0; k < V; ++k) {
                         const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
                         r[jj][k] = make_uint2(0, 0);
-                        if (c[k] > j) r[jj][k] = reinterpret_cast<const uint2 *>(ovf)[slot];
+                        if ((mk[k] >> lane) & 1ull) r[jj][k] = reinterpret_cast<const uint2 *>(ovf)[slot];
                         pre += (uint32_t)__popcll(mk[k]);
                     }
                 }
                 if (!any) break;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t j = j0 + jj;
 #pragma unroll
                     for (int k = 0; k < V; ++k) {
-                        const uint64_t at = wbase + off[k] + j0 + jj;
-                        if (c[k] > j0 + jj && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, r[jj][k].x, r[jj][k].y);
+                        const uint32_t before = B[k] & ((1u << j) - 1u);       // the matches of earlier rounds come first
+                        const uint64_t at = wbase + off[k] + (uint32_t)__popc(before);
+                        if (((B[k] >> j) & 1u) != 0 && before != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, r[jj][k].x, r[jj][k].y);
                     }
                 }
                 if (j0 + 4 > FJ_OVF_J) break;
@@ -879,6 +908,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
     __shared__ uint32_t sh_u;
     __shared__ uint32_t sh_ovf;
+    __shared__ uint32_t sh_patch;
     __shared__ uint32_t sh_grab;
     __shared__ uint32_t sh_pick;
     __shared__ uint64_t sh_base;
@@ -894,10 +924,11 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     bool pend_dup = false;
     const uint64_t *pend_ovf = nullptr;
     uint32_t *pend_table = nullptr;
+    uint32_t pend_npatch = 0;
 
     for (uint32_t iter = 0;; ++iter) {
     __syncthreads();
-    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; sh_grab = 0; }
+    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; sh_grab = 0; sh_patch = 0; }
     __syncthreads();
     const uint32_t u = sh_u;
     if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
@@ -968,9 +999,9 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             q[k] = okk[k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
         }
         O.gid = grp;
-        uint32_t run[FJ_V];
+        uint32_t run[FJ_V], bm[FJ_V];
         if (RES) fj_count_res(X, ltup, q, okk, c, flo, fhi, fp, run);
-        else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, O);
+        else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, bm, O);
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + k * WAVE + lane;
@@ -984,7 +1015,13 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             }
             mine += c[k];
             if (RES) { needs_index = needs_index || (fp[k] && c[k] >= 2u); has_dup = has_dup || c[k] >= 2u; }
-            else needs_index = needs_index || (fp[k] && c[k] >= 2u) || c[k] > FJ_OVF_J + 1u;   // its overflow entries are not where the emit pass expects them
+            else if (c[k] > FJ_OVF_J + 1u || (fp[k] && c[k] >= 2u && (MAYRES || bm[k] >= 65536u))) needs_index = true;   // matches beyond round 15: no
+            else if (!MAYRES && fp[k] && c[k] >= 2u) {                                         // overflow slot (the patch list: gather kernels only)
+                // a foreign key's tag hit between this tuple's matches: its overflow entries sit in the runs of the ROUNDS
+                // they were found in, not of their ordinals — the emit pass needs the rounds (patch list in the buffer's tail)
+                const uint32_t at = atomicAdd(&sh_patch, 1u);
+                if (at < FJ_PATCH_CAP) reinterpret_cast<uint32_t *>(O.buf + FJ_OVF_ENT)[at] = (i << 16) | bm[k];
+            }
         }
         {                                             // group total for the barrier-free emit pass
             uint32_t gt;
@@ -1001,8 +1038,8 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         if (lane == 0) wsum[w] = tot;
     }
     bool unit_needs_index = __syncthreads_or(needs_index) != 0;   // also publishes wsum
-    const uint32_t ovf_total = sh_ovf;
-    unit_needs_index = unit_needs_index || ovf_total > FJ_OVF_CAP;
+    const uint32_t ovf_total = sh_ovf, npatch = sh_patch;
+    unit_needs_index = unit_needs_index || ovf_total > FJ_OVF_ENT || npatch > FJ_PATCH_CAP;
     const bool unit_res_dup = RES && !unit_needs_index && __syncthreads_or(has_dup) != 0;
     uint64_t total = 0;
 #pragma unroll
@@ -1024,8 +1061,8 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         }
         __syncthreads();
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
-        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab, MAYRES ? 0u : pend_npatch);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab, 0u);
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)pend * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         pend = 0xffffffffu;
         __syncthreads();
@@ -1037,6 +1074,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         pend_dup = ovf_total != 0;
         pend_ovf = O.buf;
         pend_table = O.table;
+        pend_npatch = npatch;
         if (FJ_DBG && threadIdx.x == 0) { FJ_DBG[(size_t)u * 8 + 3] = FJ_DBG[(size_t)u * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
         continue;
     }
@@ -1075,8 +1113,8 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             }
         }
         __syncthreads();
-        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
-        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab);
+        if (pend_dup) fj_emit_stream<true, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab, MAYRES ? 0u : pend_npatch);
+        else          fj_emit_stream<false, N32>(f, pend, sh_base, wsum, pend_ovf, pend_table, &sh_grab, 0u);
     }
 }
 

@@ -173,6 +173,27 @@ def test_random_joins_vs_oracle(rhj, oracle, bits, nR, nS, kind, dom):
     set_path(rhj, "fused")
 
 
+def test_foreign_tag_hits_between_matches_on_the_gather_path(rhj, oracle):
+    """16 M unique R keys probing 8 M S tuples whose keys come in pairs, on 9 radix bits: build sides of 15.6 K tuples are
+    gathered (not LDS-resident), 4 M probe tuples have two matches each, and with 16-bit tags about a hundred of them meet a
+    FOREIGN key's tag hit between their matches — the tuples whose overflow entries sit in the runs of the rounds they were
+    found in (patch list of the fused kernel's streaming emit; before that the whole unit went to the index-walking emit).
+    Bit for bit against the oracle."""
+    rhj.set_bits(9)
+    R = oracle.generate(16_000_000, 0, 0, 0.0, 71)
+    rng = np.random.default_rng(72)
+    keys = np.repeat(R["value"][:4_000_000], 2)
+    rng.shuffle(keys)
+    S = np.zeros(len(keys), dtype=R.dtype)
+    S["value"] = keys
+    S["row_id"] = np.arange(len(keys), dtype=np.uint64)
+    want = oracle.join(R, S, 9)
+    assert len(want) == 8_000_000
+    set_path(rhj, "fused")
+    got = dev_join(rhj, R, S)
+    assert len(got) == len(want) and (got == want).all()
+
+
 def test_capacity_overflow_reports_count(rhj, oracle):
     rhj.set_bits(4)
     R = oracle.generate(5000, 0, 0, 0.0, 1); S = oracle.generate(9000, 1, 5000, 0.0, 2)
