@@ -126,8 +126,25 @@ def check_properties(R, S, out, m, w, bits=None):
     assert bool((R[p[:, 0], 0] == S[p[:, 1], 0]).all()), "pair joins unequal keys"
     # every S row id appears exactly once: the wrap-around sum is closed-form
     assert int(out[:, 1].sum()) == (w["nS"] * (w["nS"] - 1) // 2) % (1 << 63), "S row ids are not a permutation"
-    b = S[p[:, 1], 0] & ((1 << (bits or w["bits"])) - 1)        # (order any: the radix width the library used)
+    mask = (1 << (bits or w["bits"])) - 1                       # (order any: the radix width the library used)
+    b = S[p[:, 1], 0] & mask
     assert bool((b[1:] >= b[:-1]).all()), "buckets not ascending"
+    # the canonical order inside the buckets (row ids are input positions here): R probes where histR >= histS
+    # (rhjoin.c:86), probe tuples in input order, a tuple's matches in descending build position — on windows of consecutive pairs
+    hR = torch.bincount(R[:, 0] & mask, minlength=mask + 1)
+    hS = torch.bincount(S[:, 0] & mask, minlength=mask + 1)
+    L = min(m, 1 << 21)
+    gen = torch.Generator().manual_seed(7)
+    starts = [0, max(0, m // 2 - L // 2), max(0, m - L)] + [int(x) for x in torch.randint(0, max(1, m - L + 1), (5,), generator=gen)]
+    for a in starts:
+        win = out[a:a + L]
+        kb = S[win[:, 1], 0] & mask
+        flip = hR[kb] < hS[kb]
+        probe = torch.where(flip, win[:, 1], win[:, 0])
+        build = torch.where(flip, win[:, 0], win[:, 1])
+        same = kb[1:] == kb[:-1]
+        ok = (~same) | (probe[1:] > probe[:-1]) | ((probe[1:] == probe[:-1]) & (build[1:] < build[:-1]))
+        assert bool(ok.all()), "pairs out of canonical order inside a bucket (window at %d)" % a
 
 
 def _cpu_row(o, pyoracle, w, threads, budget_s, start_nR):

@@ -162,6 +162,11 @@ void rhj_set_subsplit(int on);
  * scan, plan, scatter and the fused join as the phases of ONE kernel launch (csrc/rhj_small.hip.h); 0: the same
  * steps as separate launches.  Results are identical either way (env RHJ_NO_SMALL=1). */
 void rhj_set_small(int on);
+/* 1 (default): a join on at most 8 radix bits whose buckets' build sides are beyond the LDS index (the reference's 4 bits
+ * from ~0.5 M tuples per relation on) runs on r + k bits internally and is emitted in the canonical order of the r bits in
+ * force (csrc/rhj_lowradix.hip.h); 0: such joins take the tiled path with hash tables in HBM.  Results are identical
+ * either way (env RHJ_NO_LOWRADIX=1). */
+void rhj_set_lowradix(int on);
 /* Pair order (env RHJ_ORDER=canonical|any).  0 = canonical (default): the reference's order for the
  * radix width in force — bucket ascending, probe side = R iff cR >= cS, probe tuples in input order, build matches
  * in descending position (rhjoin.c:42-57,86,141-250).  1 = any: the same pairs in the canonical order of a radix
@@ -192,7 +197,7 @@ typedef struct rhj_stats {
     uint64_t n_r, n_s, matches;
     uint64_t units, hbm_units, max_build, table_slots;
     int radix_bits;
-    int reserved;      /* path of the last join: 0 tiled, 1 fused, 2 | k << 8 | lo << 16 sub-split (k sub bits, pass 1 on lo bits), 3 small (fused join behind the two- or three-launch partition of csrc/rhj_small.hip.h) */
+    int reserved;      /* path of the last join: 0 tiled, 1 fused, 2 | k << 8 | lo << 16 sub-split (k sub bits, pass 1 on lo bits), 3 small (fused join behind the two- or three-launch partition of csrc/rhj_small.hip.h), 4 low-radix (csrc/rhj_lowradix.hip.h) */
 } rhj_stats;
 
 /* Join two device-resident AoS relations (rhj_tuple[nR], rhj_tuple[nS]).

@@ -67,13 +67,21 @@ struct JoinArgs {
     rhj_result_tuple*out;
     uint64_t         out_capacity;
     uint32_t         ablate;         // timing experiments only (RHJ_ABLATE): 1 no gathers, 2 no table reads
-    uint32_t         pad;
+    uint32_t         parent_mask;    // low-radix path: bucket & parent_mask = the bucket of the CALLER's radix this sub-bucket belongs to
+    const uint8_t   *parent_flip;    // low-radix path: [parent buckets] 1 = S probes; null: every bucket chooses for itself (rhjoin.c:86)
     // tiled path: what the count pass learnt per probe tuple, indexed like the partitioned relations (S behind R): the emit
     // pass takes tuples with at most one match from here and goes back to the table only for the others
     uint8_t         *stash_cnt;      // matches, saturating at 255
     uint64_t        *stash_row;      // build row id of the first match
     uint64_t         stash_nR;       // S's tuples start here
 };
+
+// Which side of bucket b is streamed (probes): R when histR >= histS, rhjoin.c:86 — decided by the bucket itself, or, when a
+// join on few radix bits is run on finer sub-buckets (rhj_lowradix.hip.h), by the caller's bucket the sub-bucket belongs to.
+__device__ __forceinline__ bool bucket_flip(const JoinArgs &a, uint32_t b, uint64_t cR, uint64_t cS)
+{
+    return a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;
+}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {

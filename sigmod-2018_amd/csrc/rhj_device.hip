@@ -80,6 +80,7 @@ struct Ctx {
                                      // default: on 100Mx100M@12 it measures 5.8 ms against 5.3 ms for the fused path (profiles/README.md r02)
     int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
     bool        stamps = false;      // env RHJ_STAMPS (diagnostics build): in-kernel phase stamps of the fused kernel, read once at load time
+    int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 512;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
     int         sub_lo = 0;          // pass-1 digit bits of the sub-split partition (0 = choose; env RHJ_SUB_LO)
@@ -91,7 +92,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     Buf sseqR, sseqS, segR, segS, sjunits, btotal, arena;
     void *pin = nullptr;            // small pinned block for read-backs
@@ -129,6 +130,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_WIDE_ROW_IDS"))) g.wide_row_ids = atoi(e);
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
+        if ((e = getenv("RHJ_NO_LOWRADIX"))) g.no_lowradix = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
         if ((e = getenv("RHJ_SMALL_TILES"))) { g.small_tiles = (uint32_t)atoi(e); if (g.small_tiles > SM_MAX_TILES) g.small_tiles = SM_MAX_TILES; }
@@ -193,6 +195,7 @@ int ctx_init()
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_lr_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_lds_bytes(PT_MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sub_join, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SJ_LDS_BYTES));
     g.ready = true;
@@ -200,6 +203,10 @@ int ctx_init()
 }
 
 struct PartState {
+    RelArgs  p2[2];          // two-pass partition: the relations as pass 2 saw them (runs, digit bytes, scanned tile counts) —
+                             // the low-radix path replays pass 2's order when it emits (rhj_lowradix.hip.h)
+    int      lo_bits = 0;    // two-pass partition: digit bits of pass 1 (0: half of the radix); the low-radix path passes the caller's radix
+    uint32_t *big_tile = nullptr;   // device word that k_hist_runs raises when a pass-2 tile exceeds one batch (or null)
     RelArgs  r[2];           // in = caller's input, out = final partitioned array
     rhj_tuple *tmp[2];       // intermediate of the two-pass path
     uint64_t *hist, *psum;   // [2][bins] of the join's radix (filled by run_partition)
@@ -290,14 +297,14 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         if (ensure(g.cntS, (size_t)ps.r[1].tiles * 256 * 4)) return -1;
         ps.r[1].cnt = (uint32_t *)g.cntS.p;
     }
-    if (bits <= PT_MAX_BITS) {
+    if (bits <= PT_MAX_BITS && !ps.lo_bits) {
         // one pass: no 12-byte intermediates and nothing that checks the row ids, so everything downstream stays wide
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&((PlanSummary *)g.summary.p)->wide_row_ids, 1, 1, g.stream));
         return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, bits, ps.hist, ps.psum, ps.plan, &ps.plan_done);
     }
 
     // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
-    const int lo = bits / 2, hi = bits - lo;
+    const int lo = ps.lo_bits ? ps.lo_bits : bits / 2, hi = bits - lo;
     const uint32_t bins1 = 1u << lo, bins2 = 1u << hi;
     uint64_t *ph = (uint64_t *)g.passhp.p, *pp = ph + 2 * 256;
     if (ensure(g.fullhist, (size_t)2 * bins * 4)) return -1;
@@ -305,6 +312,9 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     Buf *digb[2] = {&g.digR, &g.digS}, *runb[2] = {&g.runR, &g.runS}, *cntb[2] = {&g.cntR, &g.cntS};
     RelArgs *ar[2] = {&a0, &a1};
     uint32_t group = 15u * bins1 / 16u;               // a pass-2 tile averages 15/16 of 4096 tuples on uniform keys
+    // (the low-radix path replays pass 2 one batch per tile and gives up on a tile beyond 4096 tuples: 7/8 of a batch on
+    // average puts the limit 8 standard deviations away on uniform keys — at 15/16 it was 4, and 100 M tuples have 49 K tiles)
+    if (ps.lo_bits) group = 7u * bins1 / 8u;
     if (group < 1) group = 1;
     if (group > PT_MAX_GROUP - 1) group = PT_MAX_GROUP - 1;
     for (int i = 0; i < nrel; ++i) {
@@ -345,9 +355,10 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
         RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, nrel), dim3(HR_BLOCK), (size_t)bins2 * 4 * (HR_BLOCK / WAVE), g.stream,
-                   b0, b1, hi);
+                   b0, b1, hi, ps.big_tile);
     }
-    RHJ_LAUNCH(k_full_from_cnt, dim3(bins1, nrel), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
+    HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
+    RHJ_LAUNCH(k_full_from_cnt, dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
     {
         uint32_t chunks = (max2 + 15) / 16;
         if (chunks > 512) chunks = 512;
@@ -380,6 +391,7 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     }
     RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
                        ps.psum);
+    ps.p2[0] = b0; ps.p2[1] = b1;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -466,6 +478,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk;
+    pa.parent_mask = 0; pa.parent_flip = nullptr;
     // probe tuples per fused unit: whole buckets when there are plenty of them, smaller spans (each unit
     // rebuilds its bucket's index) when a low radix would otherwise leave most CUs idle
     uint32_t fused_span = FJ_SPAN;
@@ -493,7 +506,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p;
     ja.unit_flag = (uint32_t *)g.uflag.p;
     ja.out = nullptr; ja.out_capacity = 0;
-    ja.ablate = (uint32_t)g.ablate; ja.pad = 0;
+    ja.ablate = (uint32_t)g.ablate; ja.parent_mask = 0; ja.parent_flip = nullptr;
     ja.stash_cnt = nullptr; ja.stash_row = nullptr; ja.stash_nR = nR;
 
     // ---- small joins: two launches for the partition (the plan rides in the second), the fused join third, and
@@ -518,7 +531,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.pad = 0;
         fa.unit_bound = unit_bound;
         fa.host_summary = (uint64_t *)g.pin;
         fa.dbg = nullptr;
@@ -610,7 +623,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;               // words 0..7 hold the ticket
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.pad = 0;
         fa.unit_bound = unit_bound;
         fa.host_summary = nullptr;
         fa.dbg = nullptr;
@@ -856,7 +869,7 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
     RHJ_STAGE(ST_SCAN);
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);
-        RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, 2), dim3(HR_BLOCK), (size_t)D * 4 * (HR_BLOCK / WAVE), g.stream, a[0].r, a[1].r, hi);
+        RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, 2), dim3(HR_BLOCK), (size_t)D * 4 * (HR_BLOCK / WAVE), g.stream, a[0].r, a[1].r, hi, (uint32_t *)nullptr);
     }
     RHJ_LAUNCH(k_sub_colsum, dim3(bins1 << geo.kb, 2), dim3(256), 0, g.stream, a[0], a[1], geo);
     RHJ_LAUNCH(k_sub_segscan, dim3(2), dim3(1024), 0, g.stream, a[0], a[1], geo);
@@ -915,6 +928,168 @@ int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint6
 // 100M x 100M), ~6.5 K (build tuples resident in LDS beside their index) when the probe side is four times the build
 // side or more (C4: 14 bits), and for small relations up to 8 bits while an average bucket keeps 512 tuples.  The
 // result is the canonical result OF THAT RADIX: same pairs, deterministic order.
+
+// ---- the low-radix path (rhj_lowradix.hip.h) ------------------------------------------------------------------------
+// A canonical join on r <= 8 radix bits whose buckets' build sides are beyond the LDS index runs on r + k bits and is
+// emitted in the order of r bits.  Returns 2 when the path does not apply or gave up (the caller takes the tiled path).
+static int lowradix_sub_bits(int r, uint64_t nR, uint64_t nS)
+{
+    const uint64_t nmin = nR < nS ? nR : nS;
+    if (r > PT_MAX_BITS || (nmin >> r) <= 30000) return 0;                // the fused path takes such buckets as they are
+    int k = 1;
+    while (k < PT_MAX_BITS && r + k < MAX_BITS && (nmin >> (r + k)) > 20000) ++k;
+    if ((nmin >> (r + k)) > 30000) return 0;                              // even 8 more bits leave the build sides too big
+    return k;
+}
+
+int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
+                   uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches, int kb)
+{
+    rhj_stats &st = g.stats;
+    const int r = g.bits, T = r + kb;
+    const uint32_t bins = 1u << T;
+    PartState ps;
+    if (ensure(g.partR, nR * sizeof(rhj_tuple)) || ensure(g.partS, nS * sizeof(rhj_tuple)) ||
+        ensure(g.tmpR, nR * sizeof(rhj_tuple)) || ensure(g.tmpS, nS * sizeof(rhj_tuple)) || ensure(g.lr_words, 4096))
+        return -1;
+    ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0, nullptr, nullptr};
+    ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0, nullptr, nullptr};
+    ps.tmp[0] = (rhj_tuple *)g.tmpR.p; ps.tmp[1] = (rhj_tuple *)g.tmpS.p;
+    ps.lo_bits = r;                                            // pass 1 on exactly the caller's bits: pass 2 reads in canonical order
+    uint32_t *words = (uint32_t *)g.lr_words.p;                // word 0: a pass-2 tile / chunk beyond one batch; word 1: k_lr_emit's ticket
+    uint8_t *parent_flip = (uint8_t *)(words + 16);            // [2 << r]
+    ps.big_tile = words;
+    HIP_TRY(hipMemsetAsync(words, 0, 64, g.stream));
+    if (run_partition(ps, T, 2, false, true)) return -1;
+    RHJ_STAGE(ST_PLAN);
+    RHJ_LAUNCH(k_lr_parent, dim3(1u << r), dim3(256), 0, g.stream, (const uint64_t *)ps.hist, (const uint64_t *)(ps.hist + bins), r, kb, parent_flip);
+
+    const uint32_t build_chunk = 4096;
+    uint32_t lds_cap = (LDS_BUDGET - FJ_LDS_EXTRA - 128) * 2 / 9;
+    if (lds_cap > 65534) lds_cap = 65534;
+    const uint64_t nmin = nR < nS ? nR : nS;
+    const uint64_t max_units = (uint64_t)bins + (nR + nS) / PR_UNIT + 2;
+    const uint64_t max_bunits = (uint64_t)bins + nmin / build_chunk + 2;
+    const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / FJ_SPAN + 2;
+    if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) || ensure(g.ldsb, (size_t)bins * 4) ||
+        ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) || ensure(g.summary, sizeof(PlanSummary) + sizeof(SjSummary)) ||
+        ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) || ensure(g.uflag, max_units * 4) ||
+        ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) || ensure(g.status, (unit_bound + 1) * 8 + 64) ||
+        ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
+        ensure(g.walk, (unit_bound + 1) * sizeof(FjWalkItem)))
+        return -1;
+    PlanArgs pa;
+    pa.histR = ps.hist; pa.histS = ps.hist + bins;
+    pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
+    pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
+    pa.lds_cap = lds_cap; pa.lds_max_slots = LDS_BUDGET / 4 / 4 * 4; pa.build_chunk = build_chunk; pa.span_lds = FJ_SPAN;
+    pa.parent_mask = (1u << r) - 1u; pa.parent_flip = parent_flip;
+    RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, T);
+
+    JoinArgs ja;
+    ja.partR = (const rhj_tuple *)g.partR.p; ja.partS = (const rhj_tuple *)g.partS.p;
+    ja.histR = ps.hist; ja.histS = ps.hist + bins; ja.psumR = ps.psum; ja.psumS = ps.psum + bins;
+    ja.units = (const Unit *)g.units.p; ja.meta = (const BucketMeta *)g.meta.p; ja.summary = (const PlanSummary *)g.summary.p;
+    ja.tab32 = nullptr; ja.tab64 = nullptr;
+    ja.unit_count = (uint64_t *)g.ucount.p; ja.unit_base = (const uint64_t *)g.ubase.p; ja.unit_flag = (uint32_t *)g.uflag.p;
+    ja.ablate = 0; ja.parent_mask = (1u << r) - 1u; ja.parent_flip = parent_flip;
+    ja.stash_cnt = nullptr; ja.stash_row = nullptr; ja.stash_nR = nR;
+    FusedArgs fa;
+    fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
+    fa.status = (uint64_t *)g.status.p + 8; fa.ticket = (uint32_t *)g.status.p;
+    fa.nR = nR; fa.allow_resident = 0; fa.radix_bits = (uint32_t)T; fa.lr_mode = 1; fa.pad = 0;
+    fa.unit_bound = unit_bound; fa.host_summary = nullptr; fa.dbg = nullptr;
+    fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p; fa.walk = (FjWalkItem *)g.walk.p;
+    const uint32_t fused_lds = LDS_BUDGET - FJ_LDS_EXTRA;
+    const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
+    const bool count_only = !use_ctx_out && out == nullptr;
+    struct Back { PlanSummary p; uint32_t ticket[4]; uint32_t words[4]; } *hb = (Back *)g.pin;
+    uint64_t M = 0;
+    RHJ_STAGE(ST_PROBE);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // the internal join's pairs: a scratch list of their own (the emit pass reads it while it writes the caller's)
+        if (!count_only) {
+            const uint64_t guess = attempt ? M : (nR > nS ? nR : nS) + 1024;
+            if (ensure(g.lr_tmp, guess * sizeof(rhj_result_tuple))) return -1;
+        }
+        ja.out = count_only ? nullptr : (rhj_result_tuple *)g.lr_tmp.p;
+        ja.out_capacity = count_only ? 0 : g.lr_tmp.cap / sizeof(rhj_result_tuple);
+        fa.j = ja;
+        HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
+        HIP_TRY(hipMemsetAsync(g.stash_cnt.p, 0, nR + nS, g.stream));      // probe tuples of sub-buckets without a build side match nothing
+        RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+        RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+        HIP_TRY(hipMemcpyAsync(&hb->p, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(hb->ticket, g.status.p, 16, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(hb->words, words, 16, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        // what this path refuses: wide row ids, a build side beyond the LDS index, a unit that needed the index walk (its
+        // tuples' pairs are not where their stash rows say), a pass-2 tile of several batches, 2^32 pairs or more
+        if (hb->p.wide_row_ids || hb->p.row_id_overflow || !hb->p.fused_ok || hb->ticket[2] != 0 || hb->words[0] != 0 ||
+            hb->p.matches == FJ_NO_TOTAL || hb->p.matches >= (1ull << 32)) {
+            static const bool trace = getenv("RHJ_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "rhj-trace:   low-radix path gives up: wide ids %u/%u, fused_ok %llu, walk units %u, big tile %u, matches %llu\n",
+                               hb->p.wide_row_ids, hb->p.row_id_overflow, (unsigned long long)hb->p.fused_ok, hb->ticket[2], hb->words[0],
+                               (unsigned long long)hb->p.matches);
+            return 2;
+        }
+        M = hb->p.matches;
+        if (count_only || M * sizeof(rhj_result_tuple) <= g.lr_tmp.cap) break;
+    }
+    st.units = hb->p.units; st.hbm_units = 0; st.max_build = hb->p.max_build;
+    st.reserved = 4;                                           // path id: low-radix
+    *matches = M;
+    st.matches = M;
+    int rc = 0;
+    if (!count_only && M) {
+        if (use_ctx_out) {
+            if (ensure(g.out, M * sizeof(rhj_result_tuple))) return -1;
+            out = (rhj_result_tuple *)g.out.p;
+            out_capacity = M;
+            if (ctx_out) *ctx_out = out;
+        } else if (M > out_capacity) {
+            rc = 1;
+        }
+        LrArgs la;
+        la.j = ja; la.j.out = out; la.j.out_capacity = out_capacity;
+        la.p2R = ps.p2[0]; la.p2S = ps.p2[1];
+        la.stash_cnt = (const uint8_t *)g.stash_cnt.p; la.stash_row = (const uint2 *)g.stash_row.p;
+        la.tmp = (const uint4 *)g.lr_tmp.p;
+        la.nR = nR; la.r_bits = (uint32_t)r; la.k_bits = (uint32_t)kb;
+        la.slots_per_bucket = ps.p2[0].groups > ps.p2[1].groups ? ps.p2[0].groups : ps.p2[1].groups;
+        uint32_t search0 = 1;
+        while (search0 * 2 <= ps.p2[0].group) search0 *= 2;
+        la.search0 = search0;
+        const uint32_t nslots = la.slots_per_bucket << r;
+        if (ensure(g.lr_status, (size_t)nslots * 8 + 64)) return -1;
+        la.ctotal = (uint64_t *)g.lr_status.p;
+        la.bad = words;
+        RHJ_LAUNCH(k_lr_totals, dim3(nslots), dim3(256), 0, g.stream, la);
+        if (launch_offsets((const uint64_t *)g.lr_status.p, (uint64_t *)g.lr_status.p, nullptr, nslots, nslots,
+                           (uint64_t *)(words + 4)))
+            return -1;
+        const unsigned egrid = (unsigned)(nslots < (uint32_t)g.cus * 8u ? nslots : (uint32_t)g.cus * 8u);
+        RHJ_LAUNCH(k_lr_emit, dim3(egrid), dim3(LR_BLOCK), lr_lds_bytes(kb), g.stream, la, nslots);
+        RHJ_STAGE(ST_END);
+        HIP_TRY(hipMemcpyAsync(hb->words, words, 16, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (hb->words[0] != 0) return 2;
+    } else {
+        RHJ_STAGE(ST_END);
+        HIP_TRY(hipStreamSynchronize(g.stream));
+    }
+    st.radix_bits = r;
+    st.ms_hist = stage_ms(ST_HIST, ST_SCAN);
+    st.ms_scan = stage_ms(ST_SCAN, ST_SCATTER);
+    st.ms_scatter = stage_ms(ST_SCATTER, ST_PLAN);
+    st.ms_plan = stage_ms(ST_PLAN, ST_PROBE);
+    st.ms_probe = stage_ms(ST_PROBE, ST_END);
+    st.ms_total = stage_ms(ST_HIST, ST_END);
+    return rc;
+}
+
 static int auto_radix_bits(uint64_t nR, uint64_t nS)
 {
     const uint64_t nmin = nR < nS ? nR : nS, nmax = nR < nS ? nS : nR;
@@ -954,6 +1129,22 @@ static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *
         if (ctx_out) *ctx_out = nullptr;
         const int rc2 = join_device_sub(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, geo);
         if (rc2 != 2) return rc2;
+    }
+    {
+        // few radix bits over big inputs, canonical order wanted: run on finer buckets, emit in the caller's order
+        const int kb = (!g.no_lowradix && !g.no_fused && !g.force_hbm && !g.wide_row_ids && !g.range_span && nR < (1ull << 32) && nS < (1ull << 32))
+                           ? lowradix_sub_bits(g.bits, nR, nS) : 0;
+        if (kb) {
+            if (ctx_init()) return -1;
+            const float keep_h2d = g.stats.ms_h2d;
+            memset(&g.stats, 0, sizeof(g.stats));
+            g.stats.ms_h2d = keep_h2d;
+            g.stats.n_r = nR; g.stats.n_s = nS; g.stats.radix_bits = g.bits;
+            *matches = 0;
+            if (ctx_out) *ctx_out = nullptr;
+            const int rc3 = join_device_lr(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, kb);
+            if (rc3 != 2) return rc3;
+        }
     }
     int rc = join_device_once(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, g.wide_row_ids != 0, &overflow);
     if (rc >= 0 && overflow)
@@ -1060,6 +1251,7 @@ void rhj_set_fused(int on) { g.no_fused = !on; g.force_fused = on >= 2; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_subsplit(int on) { g.no_sub = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
+void rhj_set_lowradix(int on) { g.no_lowradix = !on; }
 void rhj_set_order(int any) { g.order_any = any != 0; }
 int rhj_auto_radix_bits(uint64_t nR, uint64_t nS) { return auto_radix_bits(nR, nS); }
 int rhj_get_order(void) { return g.order_any; }
@@ -1259,7 +1451,7 @@ void rhj_release(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.sseqR, &g.sseqS, &g.segR, &g.segS, &g.sjunits, &g.btotal, &g.arena, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);

@@ -52,6 +52,8 @@ struct FusedArgs {
     uint64_t  nR;
     uint32_t  allow_resident;
     uint32_t  radix_bits;     // the join's radix width (the bits every key of a bucket shares)
+    uint32_t  lr_mode;        // low-radix path (rhj_lowradix.hip.h): a tuple with several matches leaves the place of its pairs in its stash row
+    uint32_t  pad;
     uint64_t  unit_bound;     // status words there are
     uint64_t *host_summary;   // pinned host block that receives the plan summary (with the match total) at the end, or null
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
@@ -117,6 +119,11 @@ struct FjIndexT {
     uint32_t *dirw;      // [(hs + 3) / 2]
     uint32_t  hs;
     uint32_t  bits;      // the join's radix bits: shared by every key of the bucket
+    // Build sides of up to SMALL batches of 4096 tuples are read and hashed ONCE: the count pass parks (slot, tag) in the still
+    // unused entry array and the fill pass takes the words from there through registers.  Seven batches for the gather
+    // kernels — a 12-bit bucket of a 100 M relation is 24.4 K tuples: 1.2 GB of key reads and a second mix64 per build tuple
+    // less on C3, -1.9 % of the kernel (r03, A/B) — four where the resident code needs the registers.
+    static constexpr int SMALL = H32 ? 4 : 7;
     __device__ __forceinline__ hash_t hash(uint64_t key) const { return FjHashT<H32>::hash(key, bits); }
     __device__ __forceinline__ uint32_t slot(hash_t h) const { return FjHashT<H32>::slot(h, hs); }
     static __device__ __forceinline__ uint32_t tag(hash_t h) { return FjHashT<H32>::tag(h); }
@@ -207,7 +214,7 @@ __device__ __forceinline__ bool fj_round(const IX &X, uint32_t (&sn)[FJ_V], uint
 // on the way and the second pass reads them there.  `tmp` is global scratch of at least 4 * bc bytes
 // for the cooperative sort of long slots.
 constexpr uint32_t FJ_LONG = 16;                      // slots above this are filled by fetch-add and ranked afterwards
-constexpr int FJ_SMALL = 4;                           // batches of 4096 build tuples whose (slot, tag) words are kept for the fill pass
+// FJ_SMALL (FjIndexT::SMALL): batches of 4096 build tuples whose (slot, tag) words are kept in registers for the fill pass
 template <bool RES, bool N32, class IX>
 __device__ __forceinline__ void fj_build(const IX &X, const rhj_tuple *part, uint64_t boff, uint32_t bc, uint4 *ltup,
                                          uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
@@ -221,6 +228,7 @@ __device__ __forceinline__ void fj_build(const IX &X, const rhj_tuple *part, uin
     // ---- count: H[s + 1] += 1.  Build sides of up to 4 batches (16 K tuples) are hashed only once: the
     // (slot, tag) word of tuple i is parked in ent[i], picked up into registers before the fill pass
     // clears the array, and the fill pass needs neither the key nor a second hash.
+    constexpr int FJ_SMALL = IX::SMALL;
     const bool small = bc <= FJ_SMALL * FJ_BATCH;
     {
         uint4 t[FJ_V], tn[FJ_V];                       // current and prefetched batch of build tuples
@@ -660,7 +668,7 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
-    const bool flip = a.histR[b] < a.histS[b];
+    const bool flip = bucket_flip(a, b, a.histR[b], a.histS[b]);
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
     const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
     const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
@@ -739,6 +747,8 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
         for (int k = 0; k < V; ++k) {
             const uint64_t at = wbase + off[k];
             if (c[k] != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
+            if (DUP && N32 && f.lr_mode && c[k] >= 2u)     // low-radix path: k_lr_emit copies this tuple's pairs from here
+                const_cast<uint2 *>(srow)[g * 256u + k * WAVE + lane] = make_uint2((uint32_t)at, prow[k].x);
         }
         if (DUP) {
             // second and later matches: ordinal j of the group's tuples sits in one run of the overflow
@@ -803,7 +813,7 @@ __device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, con
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
-    const bool flip = a.histR[b] < a.histS[b];
+    const bool flip = bucket_flip(a, b, a.histR[b], a.histS[b]);
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
     const uint2 *pr2 = reinterpret_cast<const uint2 *>((flip ? a.partS : a.partR) + ppos);
     const uint8_t *scnt = f.stash_cnt + (flip ? f.nR : 0) + ppos;
@@ -935,7 +945,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
     const uint64_t cR = a.histR[b], cS = a.histS[b];
-    const bool flip = cR < cS;                                         // S is streamed (r_s == 1)
+    const bool flip = bucket_flip(a, b, cR, cS);                       // S is streamed (r_s == 1)
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;   // position in the probe relation
     const rhj_tuple *prp = flip ? a.partS : a.partR;                   // probe tuple i of the unit: pt_load<N32>(prp, ppos + i)
     const rhj_tuple *bdp = flip ? a.partR : a.partS;                   // build tuple i of the bucket: pt_load<N32>(bdp, bpos + i)
@@ -1174,7 +1184,7 @@ __device__ __forceinline__ void fj_walk_unit(const FusedArgs &f, uint32_t lds_by
     const Unit un = a.units[u];
     const uint32_t b = un.bucket;
     const uint64_t cR = a.histR[b], cS = a.histS[b];
-    const bool flip = cR < cS;
+    const bool flip = bucket_flip(a, b, cR, cS);
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;
     const rhj_tuple *prp = flip ? a.partS : a.partR;
     const rhj_tuple *bdp = flip ? a.partR : a.partS;

@@ -25,6 +25,8 @@ struct PlanArgs {
     uint32_t        lds_max_slots;  // LDS slot budget
     uint32_t        build_chunk;    // build tuples per 64-bit-table build unit
     uint32_t        span_lds;       // probe tuples per unit in LDS-table buckets (PR_UNIT on the tiled path)
+    uint32_t        parent_mask;    // low-radix path (see JoinArgs): the side choice of the caller's bucket
+    const uint8_t  *parent_flip;
 };
 
 constexpr uint32_t T32_PAD = 8;         // replica of the first 8 entries behind every 32-bit table
@@ -48,7 +50,8 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
     for (uint32_t b = b0; b < b1; ++b) {
         const uint64_t cR = a.histR[b], cS = a.histS[b];
         if (cR == 0 || cS == 0) continue;
-        const uint64_t pc = cR >= cS ? cR : cS, bc = cR >= cS ? cS : cR;   // rhjoin.c:86 (>=)
+        const bool flip = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;   // rhjoin.c:86 (>=)
+        const uint64_t pc = flip ? cS : cR, bc = flip ? cR : cS;
         const uint64_t span = bc <= a.lds_cap ? a.span_lds : PR_UNIT;
         nu += (pc + span - 1) / span;
         max_build = max(max_build, (uint32_t)min(bc, (uint64_t)0xffffffffu));
@@ -74,7 +77,8 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
         const uint64_t cR = a.histR[b], cS = a.histS[b];
         BucketMeta m = {0, 0, 0};
         if (cR != 0 && cS != 0) {
-            const uint64_t pc = cR >= cS ? cR : cS, bc = cR >= cS ? cS : cR;
+            const bool flip = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;
+            const uint64_t pc = flip ? cS : cR, bc = flip ? cR : cS;
             if (bc <= a.lds_cap) {
                 m.slots = lds_slots_for(bc, a.lds_max_slots);
                 m.mode = 1;

@@ -28,6 +28,8 @@
 //   rhj_join_tiled.hip.h   buckets beyond the LDS index: ordered linear-probing tag tables in HBM (Amble-Knuth order by
 //                          (tag, position) via atomic max: deterministic, duplicates meet in descending position), count and
 //                          emit passes over 1024-tuple probe tiles.
+//   rhj_lowradix.hip.h     joins on few radix bits (the reference ships 4) over inputs too big for them: run on r + k bits, emitted
+//                          in the canonical order of r bits by replaying pass 2 of the partition over the probe side.
 //   rhj_subjoin.hip.h      opt-in: partition k bits further than the join's radix, LDS-resident sub-buckets, canonical order
 //                          restored by one byte per tuple (included by rhj_device.hip behind this hub).
 //   rhj_filter.hip.h       predicate -> ballot masks -> ascending index list.
@@ -41,6 +43,7 @@
 #include "rhj_partition.hip.h"
 #include "rhj_join_tiled.hip.h"
 #include "rhj_join_fused.hip.h"
+#include "rhj_lowradix.hip.h"
 #include "rhj_small.hip.h"
 #include "rhj_filter.hip.h"
 #include "rhj_diag.hip.h"

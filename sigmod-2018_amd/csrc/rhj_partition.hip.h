@@ -394,7 +394,7 @@ __device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint
 // four digit bytes a lane), eight such loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
 // chain of dependent latencies: 6 us per tile, 0.32 ms for 100M + 100M tuples.)
 constexpr int HR_BLOCK = 256;
-__global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits)
+__global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits, uint32_t *big_tile)
 {
     extern __shared__ uint32_t lds_u32[];
     const RelArgs &r = blockIdx.y ? r1 : r0;
@@ -404,9 +404,11 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
     const uint32_t stride = gridDim.x * (HR_BLOCK / WAVE);
     for (uint32_t tile2 = blockIdx.x * (HR_BLOCK / WAVE) + w; tile2 < r.tiles; tile2 += stride) {
         for (uint32_t b = lane; b < bins; b += WAVE) h[b] = 0;
+        uint32_t tile_total = 0;
         for (uint32_t c0 = 0; c0 < r.group; c0 += WAVE) {
             uint32_t phys, len;
             pt_run_of(r, tile2, c0 + lane, phys, len);
+            tile_total += len;
             const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
 #ifdef HR_BYTE_LOADS      // the first form: one run per wave load, a byte per lane (kept for A/B)
             for (uint32_t q0 = 0; q0 < nrun; q0 += 16) {
@@ -459,27 +461,36 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
         }
         uint32_t *row = r.cnt + (size_t)tile2 * bins;
         for (uint32_t b = lane; b < bins; b += WAVE) row[b] = h[b];
+        if (big_tile) {                               // (low-radix path: it replays pass 2 one batch per tile)
+            uint32_t all;
+            wave_excl_scan_u32(tile_total, &all);
+            if (lane == 0 && all > 4096u) atomicOr(big_tile, 1u);
+        }
     }
 }
 
 // bucket histogram of the full radix = column sums of pass 2's counts per pass-1 digit
-// (grid: pass-1 digits x relations; 1024 threads = digits x slices of the tile groups)
+// (grid: pass-1 digits x relations x slices of the tile groups; 1024 threads = digits x rows; full_hist zeroed by the host:
+// with few pass-1 digits — the low-radix path has 16 — one workgroup per digit summed 1600 rows alone, 0.16 ms)
+constexpr uint32_t FH_SLICES = 8;
 __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
 {
     __shared__ uint32_t part[1024];
     const RelArgs &r = blockIdx.y ? r1 : r0;
     const uint32_t bins = 1u << bits, d = blockIdx.x;
-    const uint32_t b = threadIdx.x & (bins - 1u), slice = threadIdx.x >> bits, slices = 1024u >> bits;
+    const uint32_t b = threadIdx.x & (bins - 1u), row = threadIdx.x >> bits, rows = 1024u >> bits;
+    const uint32_t per = (r.groups + gridDim.z - 1u) / gridDim.z;
+    const uint32_t j0 = min(blockIdx.z * per, r.groups), j1 = min(j0 + per, r.groups);
     uint32_t s = 0;
     const uint32_t *base = r.cnt + (size_t)d * r.groups * bins + b;
 #pragma unroll 4
-    for (uint32_t j = slice; j < r.groups; j += slices) s += base[(size_t)j * bins];
+    for (uint32_t j = j0 + row; j < j1; j += rows) s += base[(size_t)j * bins];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < bins) {
         uint32_t t = 0;
-        for (uint32_t q = 0; q < slices; ++q) t += part[q * bins + threadIdx.x];
-        full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)] = t;
+        for (uint32_t q = 0; q < rows; ++q) t += part[q * bins + threadIdx.x];
+        if (t) atomicAdd(&full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)], t);
     }
 }
 

@@ -194,6 +194,70 @@ def test_foreign_tag_hits_between_matches_on_the_gather_path(rhj, oracle):
     assert len(got) == len(want) and (got == want).all()
 
 
+@pytest.mark.parametrize("bits,nR,nS,kind,dom,path", [
+    (4, 3_000_000, 4_000_000, 1, 3_000_000, "lowradix"),      # S probes in most buckets
+    (4, 4_000_000, 2_500_000, 1, 4_000_000, "lowradix"),      # R probes: the bigger side, Poisson matches per tuple
+    (8, 12_000_000, 16_000_000, 1, 12_000_000, "lowradix"),
+    (5, 2_500_000, 2_500_000, 4, 2_000_000, "lowradix"),      # duplicates on both sides (a few matches per tuple)
+    (4, 2_000_000, 6_000_000, 2, 2_000_000, None),            # Zipf: a pass-2 tile beyond one batch -> refused, tiled path
+    (6, 5_000_000, 5_000_000, 4, 1_500_000, None),            # heavy duplicates: tuples with more than 16 matches -> refused
+])
+def test_low_radix_path_matches_oracle(rhj, oracle, bits, nR, nS, kind, dom, path):
+    """Joins on few radix bits whose buckets are beyond the LDS index (the reference ships 4 bits): run on r + k bits, emitted
+    in the canonical order of the r bits by replaying pass 2 over the probe side (csrc/rhj_lowradix.hip.h) — bit for bit the
+    oracle's result on r bits; what the path refuses comes out of the tiled path, equally exact."""
+    rhj.set_bits(bits)
+    set_path(rhj, "fused")
+    R = oracle.generate(nR, 0 if kind != 4 else 4, dom, 0.0, 15 + bits)
+    S = oracle.generate(nS, kind, dom, 0.9, 16 + bits)
+    want = oracle.join(R, S, bits)
+    got = dev_join(rhj, R, S)
+    assert len(got) == len(want) and (got == want).all()
+    if path:
+        assert rhj.stats()["path"] == path
+    rhj.lib.rhj_set_lowradix(0)
+    try:
+        got = dev_join(rhj, R, S)
+        assert rhj.stats()["path"] != "lowradix" and len(got) == len(want) and (got == want).all()
+    finally:
+        rhj.lib.rhj_set_lowradix(1)
+
+
+def test_low_radix_multi_match_probe_tuples_and_capacity(rhj, oracle):
+    """6 M unique R keys probing 3 M S tuples whose keys come in pairs, on 4 radix bits: every matching R tuple has two
+    matches, whose pairs the emit pass copies from the internal join's list; and the capacity protocol (count, too small a
+    buffer) on this path."""
+    rhj.set_bits(4)
+    set_path(rhj, "fused")
+    R = oracle.generate(6_000_000, 0, 0, 0.0, 81)
+    keys = np.repeat(R["value"][:1_500_000], 2)
+    np.random.default_rng(82).shuffle(keys)
+    S = np.zeros(len(keys), dtype=R.dtype)
+    S["value"] = keys
+    S["row_id"] = np.arange(len(keys), dtype=np.uint64)
+    want = oracle.join(R, S, 4)
+    got = dev_join(rhj, R, S)
+    assert rhj.stats()["path"] == "lowradix"
+    assert len(got) == len(want) == 3_000_000 and (got == want).all()
+    dR, dS = rhj.to_device(R), rhj.to_device(S)
+    _, m = rhj.join_device(dR, dS, count_only=True)
+    assert m == len(want)
+    t, m = rhj.join_device(dR, dS, capacity=1000)
+    assert m == len(want) and (rhj.pairs_to_numpy(t) == want[:1000]).all()
+
+
+def test_full_size_properties_c3_on_the_shipped_4_bits(rhj):
+    """100M x 100M on the reference's own 4 radix bits (structs.h:11), canonical order, at full size through the
+    size-independent properties — incl. the order inside the 16 buckets (probe side by bucket counts, input order)."""
+    import bench
+    w = bench.WORKLOADS["c3b4"]
+    rhj.set_bits(w["bits"])
+    R, S = bench.make_relations(w, rhj.dev, 98)
+    t, m = rhj.join_device(R, S, capacity=w["nS"])
+    assert rhj.stats()["path"] == "lowradix"
+    bench.check_properties(R, S, t, m, w)
+
+
 def test_capacity_overflow_reports_count(rhj, oracle):
     rhj.set_bits(4)
     R = oracle.generate(5000, 0, 0, 0.0, 1); S = oracle.generate(9000, 1, 5000, 0.0, 2)
@@ -283,6 +347,7 @@ from pyoracle import Oracle
 o = Oracle()
 mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
 rhj.set_bits(4)
+rhj.lib.rhj_set_lowradix(0)                  # (the low-radix path would take this join: second half below)
 R = o.generate(1200000, 0, 0, 0.0, 5); S = o.generate(900000, 1, 1200000, 0.0, 6)
 t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), capacity=len(S))
 got = rhj.pairs_to_numpy(t); want = o.join(R, S, 4)
@@ -290,9 +355,11 @@ assert m == len(want) and (got == want).all()
 assert rhj.stats()["hbm_units"] > 0          # 64-bit HBM tables were really used
 print("ok")
 '''
+    code_lr = code.replace("rhj.lib.rhj_set_lowradix(0)", "pass").replace('assert rhj.stats()["hbm_units"] > 0', 'assert rhj.stats()["path"] == "lowradix"')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert res.returncode == 0 and b"ok" in res.stdout, res.stderr.decode()[-1500:]
+    for c in (code, code_lr):                # ... and the same join as a fresh process's first call on the low-radix path
+        res = subprocess.run([sys.executable, "-c", c], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert res.returncode == 0 and b"ok" in res.stdout, res.stderr.decode()[-1500:]
 
 
 def test_full_size_properties_c4(rhj):

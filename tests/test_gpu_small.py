@@ -120,9 +120,17 @@ def test_small_partition_falls_through_to_the_tiled_path(rhj, oracle):
     rng = np.random.default_rng(11)
     R, S = rel(rng, 400000, 1 << 20), rel(rng, 400000, 1 << 20)
     rhj.set_bits(1)                                    # 200 K tuples per bucket
-    got = dev_join(rhj, R, S)
-    assert rhj.stats()["path"] == "tiled"
-    same(got, oracle.join(R, S, 1), "tiled after small partition")
+    want = oracle.join(R, S, 1)
+    rhj.lib.rhj_set_lowradix(0)                        # (by default such a join runs on finer buckets: next lines)
+    try:
+        got = dev_join(rhj, R, S)
+        assert rhj.stats()["path"] == "tiled"
+        same(got, want, "tiled after small partition")
+    finally:
+        rhj.lib.rhj_set_lowradix(1)
+    got = dev_join(rhj, R, S)                          # 1 + 4 bits internally, emitted in the order of the 1 bit
+    assert rhj.stats()["path"] == "lowradix"
+    same(got, want, "low-radix path on one radix bit")
 
 
 def test_small_path_capacity_and_count_only(rhj, oracle):
