@@ -593,24 +593,21 @@ def main():
                     "pass2_scatter_runs": {"ms": stage["ms_scatter"], "moved_GBps": gbs(scatter_bytes, stage["ms_scatter"])}}
         small = st["path"] == "small"
         fused = st["path"] in ("fused", "small")
-        sub = st["path"] == "subsplit"
+        lowradix = st["path"] == "lowradix"
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
-        probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel)" if fused
-                        else "k_sub_join + k_sub_bscan + k_sub_emit (LDS-resident sub-bucket join, bucket offsets, canonical emit: the whole probe phase)" if sub
+        probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel; k_join_walk behind it returns at once on foreign-key joins)" if fused
+                        else "k_join_fused on the finer buckets + k_lr_totals + k_lr_emit (internal join, then the pairs in the canonical order "
+                             "of the caller's radix: the whole probe phase of the low-radix path)" if lowradix
                         else "k_probe<WRITE> (emit pass of the tiled path)")
-        if sub:                   # the probe phase is two kernels and a scan: the roofline is stated on their sum
-            stage["ms_probe_emit"] = stage["ms_probe"]
-            stage["ms_probe"] = join_ms
         # HBM-side bytes of the dominant kernel per launch: rocprofv3 --pmc passes of this same command,
         # committed under profiles/ (tools/pmc.sh; counters cannot be read from inside this process)
         traffic, traffic_src = None, None
         try:
             import glob
-            pat = "r*_%s_subsplit_pmc.json" if sub else "r*_%s_pmc.json"
-            cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pat % args.workload)) if sub or "subsplit" not in f)
-            if cands and (fused or sub):
+            cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.workload)) if "subsplit" not in f)
+            if cands and fused:
                 pm = json.load(open(cands[-1]))
-                want = ("k_sub_join", "k_sub_bscan", "k_sub_emit") if sub else ("k_join_fused",)
+                want = ("k_join_fused",)
                 per = {}
                 for kname, kv in pm.items():
                     if isinstance(kv, dict) and any(wk in kname for wk in want) and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
@@ -659,8 +656,6 @@ def main():
                 "plan": {"ms": stage["ms_plan"]},
                 "build_tables": {"ms": stage["ms_build"]}, "count": {"ms": stage["ms_count"]},
                 "offsets": {"ms": stage["ms_offsets"]},
-                "subsplit": ({"k_sub_join_ms": stage["ms_build"], "k_sub_bscan_ms": stage["ms_offsets"],
-                              "k_sub_emit_ms": stage.get("ms_probe_emit", 0.0)} if sub else None),
                 "gpu_total_ms": stage["ms_total"],
             },
         }

@@ -154,10 +154,6 @@ void rhj_set_force_hbm_table(int on);
 /* Fused path only: 1 (default) copies a bucket's build tuples into LDS when they fit beside
  * the index (<= ~7 K tuples: no global gather at all), 0 always gathers them from HBM. */
 void rhj_set_resident(int on);
-/* 1: joins on 9..15 radix bits with row ids below 2^32 partition k bits further than the radix so that every
- * sub-bucket's build side is LDS-resident and no candidate is gathered from memory (csrc/rhj_subjoin.hip.h);
- * 0 (default): the fused / tiled paths.  Results are identical either way (env RHJ_SUB=1). */
-void rhj_set_subsplit(int on);
 /* 1 (default): a join on at most 8 radix bits whose relations hold at most ~8 M tuples together runs histogram,
  * scan, plan, scatter and the fused join as the phases of ONE kernel launch (csrc/rhj_small.hip.h); 0: the same
  * steps as separate launches.  Results are identical either way (env RHJ_NO_SMALL=1). */
@@ -197,7 +193,7 @@ typedef struct rhj_stats {
     uint64_t n_r, n_s, matches;
     uint64_t units, hbm_units, max_build, table_slots;
     int radix_bits;
-    int reserved;      /* path of the last join: 0 tiled, 1 fused, 2 | k << 8 | lo << 16 sub-split (k sub bits, pass 1 on lo bits), 3 small (fused join behind the two- or three-launch partition of csrc/rhj_small.hip.h), 4 low-radix (csrc/rhj_lowradix.hip.h) */
+    int reserved;      /* path of the last join: 0 tiled, 1 fused, 3 small (fused join behind the two- or three-launch partition of csrc/rhj_small.hip.h), 4 low-radix (csrc/rhj_lowradix.hip.h) */
 } rhj_stats;
 
 /* Join two device-resident AoS relations (rhj_tuple[nR], rhj_tuple[nS]).

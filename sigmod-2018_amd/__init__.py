@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "RadixHashJoin", "Filter", "InsertResult", "InsertRowIdResult", "GetResultNum", "FindResultRowId",
     "FindResultTuples", "FreeResult", "PrintResult", "FreeRelation", "SchedulerInit", "SchedulerDestroy",
     "rhj_set_radix_bits", "rhj_get_radix_bits", "rhj_set_empty_mode", "rhj_set_node_pairs", "rhj_set_device", "rhj_get_device",
-    "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_subsplit", "rhj_set_small", "rhj_set_lowradix", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_partition_device", "rhj_filter_device",
+    "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_small", "rhj_set_lowradix", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_partition_device", "rhj_filter_device",
     "rhj_register_relation_map", "rhj_unregister_relation_map", "rhj_registered_columns", "rhj_pinned_ranges",
     "rhj_bucket_histogram_device", "rhj_select_bucket_range_device", "rhj_join_device_range", "rhj_pin_refusals",
     "rhj_release", "rhj_last_stats", "rhj_version",
@@ -86,7 +86,7 @@ class Stats(C.Structure):
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
         r = self.reserved                  # path of the last join (include/rhj.h)
-        d["path"] = {0: "tiled", 1: "fused", 2: "subsplit", 3: "small", 4: "lowradix"}.get(r & 0xff, "?")
+        d["path"] = {0: "tiled", 1: "fused", 3: "small", 4: "lowradix"}.get(r & 0xff, "?")
         d["sub_bits"], d["pass1_bits"] = (r >> 8) & 0xff, (r >> 16) & 0xff
         return d
 
@@ -129,7 +129,6 @@ def load_library(path=None):
     L.rhj_set_force_hbm_table.argtypes = [C.c_int]
     L.rhj_set_fused.argtypes = [C.c_int]
     L.rhj_set_resident.argtypes = [C.c_int]
-    L.rhj_set_subsplit.argtypes = [C.c_int]
     L.rhj_set_small.argtypes = [C.c_int]
     L.rhj_set_lowradix.argtypes = [C.c_int]
     L.rhj_set_order.argtypes = [C.c_int]

@@ -5,7 +5,6 @@
 // There is no CPU fallback: any HIP failure is reported on stderr and returned as
 // an error; a missing GPU makes every entry point fail.
 #include "rhj_kernels.hip.h"
-#include "rhj_subjoin.hip.h"
 #include "rhj_shard_kernels.hip.h"
 #include "rhj_internal.h"
 #include <mutex>
@@ -51,6 +50,13 @@ static void debug_after_launch(const char *what, hipStream_t s)
         debug_after_launch(#kernel, stream);                                     \
     } while (0)
 
+// kernels compiled apart for sharded joins (template <bool RANGED>): the ordinary form when the range is the whole radix
+#define RHJ_LAUNCH_RANGED(kernel, ranged, grid, block, lds, stream, ...)        \
+    do {                                                                         \
+        if (ranged) RHJ_LAUNCH((kernel<true>), grid, block, lds, stream, __VA_ARGS__);   \
+        else        RHJ_LAUNCH((kernel<false>), grid, block, lds, stream, __VA_ARGS__);  \
+    } while (0)
+
 struct Buf {
     void  *p = nullptr;
     size_t cap = 0;
@@ -76,16 +82,11 @@ struct Ctx {
     int         force_fused = 0;     // rhj_set_fused(2): the fused path even where the tiled one is expected to be faster (tiny buckets)
     int         no_resident = 0;
     int         wide_row_ids = 0;    // 1: never use 12-byte intermediates (env RHJ_WIDE_ROW_IDS)
-    int         no_sub = 1;          // 0: take the sub-split path where it applies (env RHJ_SUB=1, rhj_set_subsplit(1)); off by
-                                     // default: on 100Mx100M@12 it measures 5.8 ms against 5.3 ms for the fused path (profiles/README.md r02)
     int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
     bool        stamps = false;      // env RHJ_STAMPS (diagnostics build): in-kernel phase stamps of the fused kernel, read once at load time
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 512;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
-    int         sub_lo = 0;          // pass-1 digit bits of the sub-split partition (0 = choose; env RHJ_SUB_LO)
-    int         sub_k = -1;          // sub bits (-1 = choose from the relation sizes; env RHJ_SUB_K)
-    uint32_t    sub_target = 3100;   // average build tuples per sub-bucket aimed at
     uint32_t    range_lo = 0, range_span = 0;   // rhj_join_device_range: the buckets this call joins (span 0: all of them)
     int         cus = 256;           // compute units of the device (one fused workgroup each)
     uint64_t    node_pairs = 65535;
@@ -94,7 +95,6 @@ struct Ctx {
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
         ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
-    Buf sseqR, sseqS, segR, segS, sjunits, btotal, arena;
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // D2H staging of result pairs (16 MiB each)
     hipEvent_t ev_ring[4] = {};
@@ -134,11 +134,6 @@ struct EnvDefaults {
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
         if ((e = getenv("RHJ_SMALL_TILES"))) { g.small_tiles = (uint32_t)atoi(e); if (g.small_tiles > SM_MAX_TILES) g.small_tiles = SM_MAX_TILES; }
-        if ((e = getenv("RHJ_SUB"))) g.no_sub = !atoi(e);
-        if ((e = getenv("RHJ_NO_SUB"))) g.no_sub = atoi(e);
-        if ((e = getenv("RHJ_SUB_LO"))) g.sub_lo = atoi(e);
-        if ((e = getenv("RHJ_SUB_K"))) g.sub_k = atoi(e);
-        if ((e = getenv("RHJ_SUB_TARGET"))) g.sub_target = (uint32_t)atoi(e);
     }
 } env_defaults;
 
@@ -190,14 +185,14 @@ int ctx_init()
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_small_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(PT_MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_lr_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_lds_bytes(PT_MAX_BITS)));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sub_join, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SJ_LDS_BYTES));
     g.ready = true;
     return 0;
 }
@@ -242,11 +237,11 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
     if (plan && nrel == 2 && max_tiles <= SMALL_TILES) {
         // small join: histogram, {scans + plan} in one single-workgroup launch, scatter — three launches instead of seven
         RHJ_STAGE(ST_HIST);
-        RHJ_LAUNCH(k_hist_tiles, dim3(max_tiles, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
+        RHJ_LAUNCH_RANGED(k_hist_tiles, r0.range_span, dim3(max_tiles, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
         RHJ_STAGE(ST_SCAN);
         RHJ_LAUNCH(k_small_scan_plan, dim3(1), dim3(1024), 0, g.stream, r0, r1, bits, hist, psum, *plan);
         RHJ_STAGE(ST_SCATTER);
-        RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
+        RHJ_LAUNCH_RANGED(k_scatter_lds, r0.range_span, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
         HIP_TRY(hipGetLastError());
         *plan_done = true;
         return 0;
@@ -257,7 +252,7 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
     if (ensure(g.chunk, (size_t)2 * chunks * bins * 8)) return -1;
     const uint32_t hist_grid = max_tiles < 2048 ? max_tiles : 2048;
     RHJ_STAGE(ST_HIST);
-    RHJ_LAUNCH(k_hist_tiles, dim3(hist_grid, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
+    RHJ_LAUNCH_RANGED(k_hist_tiles, r0.range_span, dim3(hist_grid, nrel), dim3(256), (size_t)bins * 4, g.stream, r0, r1, 0, bits);
     RHJ_STAGE(ST_SCAN);
     RHJ_LAUNCH(k_scan_chunks, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (uint64_t *)g.chunk.p);
@@ -266,7 +261,7 @@ int partition_pass(RelArgs r0, RelArgs r1, int nrel, int bits, uint64_t *hist, u
     RHJ_LAUNCH(k_scan_apply, dim3((bins + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, r0, r1, bits,
                        chunks, (const uint64_t *)g.chunk.p, (const uint64_t *)psum);
     RHJ_STAGE(ST_SCATTER);
-    RHJ_LAUNCH(k_scatter_lds, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
+    RHJ_LAUNCH_RANGED(k_scatter_lds, r0.range_span, dim3(max_tiles, nrel), dim3(PT_BLOCK), scatter_lds_bytes(bits), g.stream, r0, r1, 0, bits);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -350,7 +345,10 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
     RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
-    RHJ_LAUNCH(k_local_part, dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
+    if (a0.range_span)
+        RHJ_LAUNCH((k_local_part<true>), dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
+    else
+        RHJ_LAUNCH((k_local_part<false>), dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
     RHJ_STAGE(ST_SCAN);
     {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
@@ -470,7 +468,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     const uint64_t max_tab32 = nmin + nmin / 2 + (uint64_t)80 * bins + 64;
     if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) ||
         ensure(g.ldsb, (size_t)bins * 4) || ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) ||
-        ensure(g.summary, sizeof(PlanSummary) + sizeof(SjSummary)) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
+        ensure(g.summary, sizeof(PlanSummary) + 64) || ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) ||
         ensure(g.uflag, max_units * 4) || ensure(g.histpsum, (size_t)4 * bins * 8))
         return -1;
     PlanArgs pa;
@@ -768,167 +766,6 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     return rc;
 }
 
-// ---- the sub-split path (rhj_subjoin.hip.h) -----------------------------------------------------------------------
-// Geometry: k sub bits so that an average sub-bucket's build side is about g.sub_target tuples (and bits + k >= 13: the
-// LDS index is exact from 13 shared bits on), pass 1 on `lo` bits, pass 2 on the other bits of the radix plus the sub bits.
-static bool sub_geometry(int bits, uint64_t nR, uint64_t nS, SubGeom *geo)
-{
-    if (g.no_sub || g.force_hbm || g.no_fused || bits <= PT_MAX_BITS) return false;
-    const uint64_t nmin = nR < nS ? nR : nS;
-    int k = 0;
-    while (k < 6 && (nmin >> (bits + k)) > g.sub_target) ++k;
-    if (bits + k < 13) k = 13 - bits;
-    if (g.sub_k >= 0) k = g.sub_k;
-    const int t = bits + k;
-    if (t < 13 || t > 16 || k > 5) return false;
-    int lo = g.sub_lo ? g.sub_lo : t / 2;
-    if (lo > bits - 1) lo = bits - 1;
-    if (lo < t - 8) lo = t - 8;
-    if (lo < 1 || lo > 8 || t - lo > 8 || bits - lo < 1) return false;
-    geo->lo = lo; geo->hb = bits - lo; geo->kb = k;
-    return true;
-}
-
-// 0 done, 2 the plan refused (the caller runs the fused / tiled path), 1 output capacity too small, < 0 error
-int join_device_sub(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64_t nS, rhj_result_tuple *out,
-                    uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches, SubGeom geo)
-{
-    rhj_stats &st = g.stats;
-    const int bits = geo.lo + geo.hb, hi = geo.hb + geo.kb, t = bits + geo.kb;
-    const uint32_t bins = 1u << bits, bins1 = 1u << geo.lo, D = 1u << hi;
-    const uint64_t n[2] = {nR, nS};
-    const rhj_tuple *din[2] = {dR, dS};
-    Buf *tmpb[2] = {&g.tmpR, &g.tmpS}, *partb[2] = {&g.partR, &g.partS}, *digb[2] = {&g.digR, &g.digS},
-        *runb[2] = {&g.runR, &g.runS}, *cntb[2] = {&g.cntR, &g.cntS}, *sqb[2] = {&g.sseqR, &g.sseqS}, *segb[2] = {&g.segR, &g.segS};
-    uint32_t group = 15u * bins1 / 16u;
-    if (group < 1) group = 1;
-    if (group > PT_MAX_GROUP - 1) group = PT_MAX_GROUP - 1;
-    SubRel a[2];                                       // pass 1 view (r.in = caller's tuples) and pass 2 view share the run fields
-    RelArgs p1[2];
-    uint32_t max1 = 0, max2 = 0;
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t tiles1 = tiles_for(n[i]);
-        const uint32_t groups = (tiles1 + group - 1) / group;
-        if (ensure(*tmpb[i], n[i] * 16 + 64) /* pass 1 writes 16-byte tuples when the sample finds wide row ids */ || ensure(*partb[i], n[i] * 12 + 64) || ensure(*digb[i], n[i] + 64) ||
-            ensure(*runb[i], (size_t)tiles1 * (bins1 + 1) * 2 + 64) || ensure(*cntb[i], (size_t)bins1 * groups * D * 4) ||
-            ensure(*sqb[i], n[i] + 64) || ensure(*segb[i], (size_t)2 * bins1 * D * 4))
-            return -1;
-        RelArgs r = RelArgs{};
-        r.in = din[i]; r.out = (rhj_tuple *)tmpb[i]->p; r.n = n[i]; r.tiles = tiles1;
-        r.dig_out = (uint8_t *)digb[i]->p; r.runs = (uint16_t *)runb[i]->p; r.cnt = (uint32_t *)cntb[i]->p;
-        r.tiles1 = tiles1; r.group = group; r.groups = groups;
-        p1[i] = r;
-        RelArgs q = r;
-        q.in = (const rhj_tuple *)tmpb[i]->p; q.out = (rhj_tuple *)partb[i]->p;
-        q.dig_in = (const uint8_t *)digb[i]->p; q.dig_out = nullptr;
-        q.tiles = bins1 * groups;
-        a[i].r = q;
-        a[i].sseq = (uint8_t *)sqb[i]->p;
-        a[i].segsum = (uint32_t *)segb[i]->p;
-        a[i].segbase = a[i].segsum + (size_t)bins1 * D;
-        if (tiles1 > max1) max1 = tiles1;
-        if (q.tiles > max2) max2 = q.tiles;
-    }
-    const uint32_t nsub = 1u << t;
-    const uint64_t extra_cap = (nR + nS) / SJ_SPAN + 2;
-    // u32 entries: one per match of a tuple with several (a join that needs more than one per tuple of the larger relation
-    // falls back)
-    const uint64_t arena_cap = (nR > nS ? nR : nS) + (1u << 20);
-    const size_t desc_bytes = (size_t)nsub * sizeof(SjDesc), bdesc_bytes = (size_t)bins * sizeof(SjBucket);
-    if (ensure(g.summary, sizeof(PlanSummary) + sizeof(SjSummary)) || ensure(g.sjunits, desc_bytes + bdesc_bytes + extra_cap * sizeof(SjExtra)) ||
-        ensure(g.btotal, (size_t)2 * bins * 8) || ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
-        ensure(g.arena, arena_cap * 4 + 64))
-        return -1;
-    PlanSummary *dsum = (PlanSummary *)g.summary.p;
-    SjSummary *dsj = (SjSummary *)(dsum + 1);
-    HIP_TRY(hipMemsetAsync(&dsum->wide_row_ids, 0, 8, g.stream));            // wide_row_ids, row_id_overflow
-    HIP_TRY(hipMemsetAsync(g.btotal.p, 0, (size_t)bins * 8, g.stream));
-    HIP_TRY(hipMemsetAsync(dsj, 0, sizeof(SjSummary), g.stream));
-    if (use_ctx_out) {
-        const uint64_t guess = (nR > nS ? nR : nS) + 1024;
-        if (g.out.cap < guess * sizeof(rhj_result_tuple) && ensure(g.out, guess * sizeof(rhj_result_tuple))) return -1;
-        out = (rhj_result_tuple *)g.out.p;
-        out_capacity = g.out.cap / sizeof(rhj_result_tuple);
-    }
-    SjArgs sa;
-    sa.partR = (const Tuple12 *)g.partR.p; sa.partS = (const Tuple12 *)g.partS.p;
-    sa.segsumR = a[0].segsum; sa.segsumS = a[1].segsum; sa.segbaseR = a[0].segbase; sa.segbaseS = a[1].segbase;
-    sa.sseqR = a[0].sseq; sa.sseqS = a[1].sseq;
-    sa.desc = (SjDesc *)g.sjunits.p; sa.bdesc = (SjBucket *)((char *)g.sjunits.p + desc_bytes);
-    sa.extra = (SjExtra *)((char *)g.sjunits.p + desc_bytes + bdesc_bytes); sa.extra_cap = (uint32_t)extra_cap;
-    sa.summary = dsum; sa.sj = dsj;
-    sa.stash_cnt = (uint8_t *)g.stash_cnt.p; sa.stash_row = (uint2 *)g.stash_row.p;
-    sa.arena = (uint32_t *)g.arena.p; sa.arena_cap = arena_cap;
-    sa.btotal = (unsigned long long *)g.btotal.p; sa.obase = (uint64_t *)g.btotal.p + bins;
-    sa.out = out; sa.out_capacity = out ? out_capacity : 0;
-    sa.nR = nR; sa.g = geo; sa.max_bucket = 1u << 20;
-
-    RHJ_STAGE(ST_HIST);
-    RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, p1[0], p1[1], 2, 0, dsum);
-    RHJ_LAUNCH(k_local_part, dim3(max1, 2), dim3(PT_BLOCK), scatter_lds_bytes(geo.lo), g.stream, p1[0], p1[1], 0, geo.lo, geo.lo, hi, dsum);
-    RHJ_STAGE(ST_SCAN);
-    {
-        const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);
-        RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, 2), dim3(HR_BLOCK), (size_t)D * 4 * (HR_BLOCK / WAVE), g.stream, a[0].r, a[1].r, hi, (uint32_t *)nullptr);
-    }
-    RHJ_LAUNCH(k_sub_colsum, dim3(bins1 << geo.kb, 2), dim3(256), 0, g.stream, a[0], a[1], geo);
-    RHJ_LAUNCH(k_sub_segscan, dim3(2), dim3(1024), 0, g.stream, a[0], a[1], geo);
-    RHJ_LAUNCH(k_sub_apply, dim3(bins1 << geo.kb, 2), dim3(256), 0, g.stream, a[0], a[1], geo);
-    RHJ_STAGE(ST_SCATTER);
-    uint32_t search0 = 1;
-    while (search0 * 2 <= group) search0 *= 2;
-    {
-        uint32_t per_cu = (uint32_t)(LDS_BUDGET / SS_LDS_BYTES);               // the workgroups that are resident together
-        if (per_cu > 2048u / SS_BLOCK) per_cu = 2048u / SS_BLOCK;
-        if (per_cu < 1) per_cu = 1;
-        const uint32_t sgrid = (uint32_t)g.cus * per_cu;
-        const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;
-        RHJ_LAUNCH(k_scatter_sub, dim3(want, 2), dim3(SS_BLOCK), SS_LDS_BYTES, g.stream, a[0], a[1], geo, search0, (const PlanSummary *)dsum);
-    }
-    RHJ_STAGE(ST_PLAN);
-    RHJ_LAUNCH(k_sub_plan, dim3((nsub + 255) / 256), dim3(256), 0, g.stream, sa);
-    RHJ_STAGE(ST_BUILD);
-    RHJ_LAUNCH(k_sub_join, dim3((unsigned)(nsub + extra_cap)), dim3(SJ_BLOCK), SJ_LDS_BYTES, g.stream, sa, nsub);
-    RHJ_STAGE(ST_OFFSETS);
-    RHJ_LAUNCH(k_sub_bscan, dim3(1), dim3(1024), 0, g.stream, sa);
-    RHJ_STAGE(ST_PROBE);
-    if (out) RHJ_LAUNCH(k_sub_emit, dim3(bins), dim3(SE_BLOCK), 0, g.stream, sa);
-    RHJ_STAGE(ST_END);
-    struct Back { PlanSummary p; SjSummary s; } *hb = (Back *)g.pin;
-    HIP_TRY(hipMemcpyAsync(hb, g.summary.p, sizeof(Back), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    if (hb->s.bad || hb->p.wide_row_ids || hb->p.row_id_overflow) return 2;
-    const uint64_t M = hb->s.matches;
-    if (use_ctx_out && M > out_capacity) return 2;     // rare: fan-out above the guess; the other path sizes the buffer from its count
-    *matches = M;
-    st.matches = M;
-    st.units = nsub + hb->s.extra; st.hbm_units = 0; st.max_build = hb->s.max_build;
-    st.reserved = 2 | (geo.kb << 8) | (geo.lo << 16);
-    if (ctx_out) *ctx_out = out;
-    st.ms_hist = stage_ms(ST_HIST, ST_SCAN);
-    st.ms_scan = stage_ms(ST_SCAN, ST_SCATTER);
-    st.ms_scatter = stage_ms(ST_SCATTER, ST_PLAN);
-    st.ms_plan = stage_ms(ST_PLAN, ST_BUILD);
-    st.ms_build = stage_ms(ST_BUILD, ST_OFFSETS);
-    st.ms_offsets = stage_ms(ST_OFFSETS, ST_PROBE);
-    st.ms_probe = stage_ms(ST_PROBE, ST_END);
-    st.ms_total = stage_ms(ST_HIST, ST_END);
-    return (!use_ctx_out && out && M > out_capacity) ? 1 : 0;
-}
-
-// The two-pass partition keeps 12-byte tuples between its passes when the row ids fit 32 bits (decided
-// on the device from a sample).  If a wider row id went through anyway, the pairs carry truncated row
-// ids: the join is run again with 16-byte intermediates.
-// Order mode "any" (rhj_set_order(1), env RHJ_ORDER=any): the caller wants the pairs, not the reference's pair order
-// — the order is a function of N_LSB (bucket-major, side choice per bucket), and a caller who does not depend on it
-// should not pay for a radix chosen for a CPU cache: 100M x 100M takes 23.5 ms on the reference's 4 bits (buckets of
-// 6 M tuples: tables in HBM) and 5.2 ms on 12-13.  The radix is then the library's choice from the relation sizes:
-// build sides of ~16 K tuples per bucket (the fused kernel's best on equal sizes, tools/exp: 12 and 13 bits tie on
-// 100M x 100M), ~6.5 K (build tuples resident in LDS beside their index) when the probe side is four times the build
-// side or more (C4: 14 bits), and for small relations up to 8 bits while an average bucket keeps 512 tuples.  The
-// result is the canonical result OF THAT RADIX: same pairs, deterministic order.
-
 // ---- the low-radix path (rhj_lowradix.hip.h) ------------------------------------------------------------------------
 // A canonical join on r <= 8 radix bits whose buckets' build sides are beyond the LDS index runs on r + k bits and is
 // emitted in the order of r bits.  Returns 2 when the path does not apply or gave up (the caller takes the tiled path).
@@ -972,7 +809,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     const uint64_t max_bunits = (uint64_t)bins + nmin / build_chunk + 2;
     const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / FJ_SPAN + 2;
     if (ensure(g.units, max_units * sizeof(Unit)) || ensure(g.bunits, max_bunits * sizeof(Unit)) || ensure(g.ldsb, (size_t)bins * 4) ||
-        ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) || ensure(g.summary, sizeof(PlanSummary) + sizeof(SjSummary)) ||
+        ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) || ensure(g.summary, sizeof(PlanSummary) + 64) ||
         ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) || ensure(g.uflag, max_units * 4) ||
         ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) || ensure(g.status, (unit_bound + 1) * 8 + 64) ||
         ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
@@ -1118,18 +955,6 @@ static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *
                              uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
 {
     bool overflow = false;
-    SubGeom geo;
-    if (nR && nS && nR < (1ull << 32) && nS < (1ull << 32) && !g.wide_row_ids && !g.range_span && sub_geometry(g.bits, nR, nS, &geo)) {
-        if (ctx_init()) return -1;
-        const float keep_h2d = g.stats.ms_h2d;
-        memset(&g.stats, 0, sizeof(g.stats));
-        g.stats.ms_h2d = keep_h2d;
-        g.stats.n_r = nR; g.stats.n_s = nS; g.stats.radix_bits = g.bits;
-        *matches = 0;
-        if (ctx_out) *ctx_out = nullptr;
-        const int rc2 = join_device_sub(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, geo);
-        if (rc2 != 2) return rc2;
-    }
     {
         // few radix bits over big inputs, canonical order wanted: run on finer buckets, emit in the caller's order
         const int kb = (!g.no_lowradix && !g.no_fused && !g.force_hbm && !g.wide_row_ids && !g.range_span && nR < (1ull << 32) && nS < (1ull << 32))
@@ -1249,7 +1074,6 @@ void rhj_set_node_pairs(uint64_t pairs) { g.node_pairs = pairs; }
 void rhj_set_force_hbm_table(int on) { g.force_hbm = on; }
 void rhj_set_fused(int on) { g.no_fused = !on; g.force_fused = on >= 2; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
-void rhj_set_subsplit(int on) { g.no_sub = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
 void rhj_set_lowradix(int on) { g.no_lowradix = !on; }
 void rhj_set_order(int any) { g.order_any = any != 0; }
@@ -1452,7 +1276,7 @@ void rhj_release(void)
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
                   &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
-                  &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.sseqR, &g.sseqS, &g.segR, &g.segS, &g.sjunits, &g.btotal, &g.arena, &g.fmask, &g.ftile, &g.fbase, &g.fout};
+                  &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);
     g.columns.clear();

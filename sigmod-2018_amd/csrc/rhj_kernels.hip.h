@@ -30,8 +30,6 @@
 //                          emit passes over 1024-tuple probe tiles.
 //   rhj_lowradix.hip.h     joins on few radix bits (the reference ships 4) over inputs too big for them: run on r + k bits, emitted
 //                          in the canonical order of r bits by replaying pass 2 of the partition over the probe side.
-//   rhj_subjoin.hip.h      opt-in: partition k bits further than the join's radix, LDS-resident sub-buckets, canonical order
-//                          restored by one byte per tuple (included by rhj_device.hip behind this hub).
 //   rhj_filter.hip.h       predicate -> ballot masks -> ascending index list.
 // Tags only pre-filter everywhere: every candidate is verified against the build tuple's full 64-bit key, so results are exact
 // for any hash and any tag collision.

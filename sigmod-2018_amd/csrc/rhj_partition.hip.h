@@ -34,6 +34,8 @@ __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok, int bits)
 }
 
 // Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
+// (RANGED: a sharded join — tuples of another rank's buckets are not counted; compiled apart, see k_local_part)
+template <bool RANGED>
 __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits)
 {
     extern __shared__ uint32_t lds_u32[];
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int 
 #pragma unroll 4
         for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
             const uint32_t k = (uint32_t)(r.in[i].value >> shift);
-            if (r.range_span && ((k & mask) - r.range_lo) >= r.range_span) continue;   // sharded join: another rank's bucket
+            if (RANGED && ((k & mask) - r.range_lo) >= r.range_span) continue;   // sharded join: another rank's bucket
             atomicAdd(&tile_h[k & mask], 1u);
         }
         __syncthreads();
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(1024) void k_full_psum(int bits, const uint32_t *fu
 //   wave) + (same digit in lower lanes of this round)
 // computed with one match-any (bits ballots) per round and per-wave LDS counters — no
 // atomics, so the placement does not depend on any hardware ordering.
+template <bool RANGED>
 __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1, int shift, int bits)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
     for (int k = 0; k < PT_V; ++k) {
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch)
         const uint32_t d = (uint32_t)(key >> shift) & mask;
-        if (r.range_span) ok[k] = ok[k] && (d - r.range_lo) < r.range_span;      // sharded join: another rank's buckets are dropped here
+        if (RANGED) ok[k] = ok[k] && (d - r.range_lo) < r.range_span;         // sharded join: another rank's buckets are dropped here
         dig[k] = d;
         const uint64_t peers = digit_peers(d, ok[k], bits);
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
     __syncthreads();
 
     uint4 *out = reinterpret_cast<uint4 *>(r.out);
-    const uint32_t kept = (uint32_t)kept64;
+    const uint32_t kept = RANGED ? (uint32_t)kept64 : count;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t p = k * PT_BLOCK + threadIdx.x;
@@ -277,6 +280,10 @@ __global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, in
 // scatter over these tiles give the final array.  Compared with two offset-driven passes this drops
 // the first pass' histogram read of both relations and turns the first pass' scattered run writes
 // into streaming writes; pass 2 reads 1 KiB runs instead of a contiguous tile.
+// RANGED: a sharded join (rhj_join_device_range) — only the tuples whose bucket, the low shift + bits + next_bits key bits, lies
+// in the rank's range go on; the tile shrinks in place, its run table says by how much, and everything downstream reads runs.
+// Compiled apart: the test in the ordinary kernel cost it 27 % on 100M x 1B (r03: 5.7 -> 7.3 ms) although it never fires there.
+template <bool RANGED>
 __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
                                                          PlanSummary *summary)
 {
@@ -309,16 +316,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     }
     __syncthreads();
 
-    // sharded join (rhj_join_device_range): only the tuples whose bucket — the low shift + bits + next_bits key bits — lies in
-    // the rank's range go on; the tile shrinks in place, its run table says by how much, and everything downstream reads runs
-    const uint32_t full_mask = (1u << (shift + bits + next_bits)) - 1u;
     uint32_t lrank[PT_V], dig[PT_V];
     uint32_t *mycnt = wcnt + w * bins;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
-        if (r.range_span) ok[k] = ok[k] && (((uint32_t)key & full_mask) - r.range_lo) < r.range_span;
+        if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << (shift + bits + next_bits)) - 1u)) - r.range_lo) < r.range_span;
         dig[k] = d;
         uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
         for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     }
     uint64_t kept64;                                      // the tile's tuples that stay (all of them unless the join is sharded)
     const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, &kept64, sm);
-    const uint32_t kept = (uint32_t)kept64;
+    const uint32_t kept = RANGED ? (uint32_t)kept64 : count;
     if (threadIdx.x < bins) dstart[threadIdx.x] = (uint32_t)ds;
     if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : kept);
     __syncthreads();
@@ -375,7 +379,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     }
     if (T12 && __ballot(wide) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->row_id_overflow, 1u);
 }
-
 // pass-2 tile -> its runs: thread i < group describes run i (two coalesced reads of the transposed table)
 __device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint32_t i, uint32_t &phys, uint32_t &len)
 {

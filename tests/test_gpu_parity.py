@@ -474,46 +474,6 @@ def test_entry_points_from_several_host_threads(rhj, oracle):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("bits,nR,nS,kind,dom", [
-    (12, 300_000, 400_000, "fk", 0),            # k = 1: 13 shared bits, the smallest geometry the LDS index is exact for
-    (12, 2_000_000, 3_000_000, "fk", 0),        # several hundred tuples per sub-bucket, both probe directions
-    (9, 600_000, 600_000, "fk", 0),             # 9 radix bits + 4 sub bits
-    (15, 1_000_000, 1_500_000, "fk", 0),        # no sub bits at all (k = 0): pass 2 on the radix' own upper 8 bits
-    (12, 500_000, 500_000, "dups", 250_000),    # ~2 duplicates per key on both sides: arena runs
-    (12, 500_000, 500_000, "dups", 40_000),     # ~12 per key: more matches than the arena holds -> falls back
-    (13, 200_000, 2_000_000, "zipf", 0),        # skewed probe side: spans of a long probe side, multi-step K2
-    (12, 150_000, 150_000, "dups", 300),        # 500 duplicates per key: counts above 254, build sides above the LDS cap -> falls back
-    (12, 400_000, 400_000, "wide", 0),          # row ids of 2^40 and more: pass 1 keeps 16-byte tuples -> falls back
-])
-def test_subsplit_path_matches_oracle(rhj, oracle, bits, nR, nS, kind, dom):
-    """The sub-split path (csrc/rhj_subjoin.hip.h; opt-in) against the oracle, bit for bit, and that it is the path
-    that ran (rhj_stats.reserved) — or that it handed the join to the fused path where its plan has to refuse."""
-    rhj.set_bits(bits)
-    if kind in ("fk", "wide"):
-        R, S = oracle.generate(nR, 0, 0, 0.0, 71), oracle.generate(nS, 1, nR, 0.0, 72)
-        if kind == "wide":
-            R["row_id"] += np.uint64(1) << np.uint64(40)
-    elif kind == "zipf":
-        R, S = oracle.generate(nR, 0, 0, 0.0, 73), oracle.generate(nS, 2, nR, 0.9, 74)
-    else:
-        R, S = oracle.generate(nR, 4, dom, 0.0, 75), oracle.generate(nS, 4, dom, 0.0, 76)
-        R["value"] = R["value"] * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)      # spread over all 64 bits
-        S["value"] = S["value"] * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
-    want = oracle.join(R, S, bits)
-    dR, dS = rhj.to_device(R), rhj.to_device(S)
-    rhj.lib.rhj_set_subsplit(1)
-    try:
-        t, m = rhj.join_device(dR, dS)
-        path = rhj.stats()["path"]
-        got = rhj.pairs_to_numpy(t)
-    finally:
-        rhj.lib.rhj_set_subsplit(0)
-    assert m == len(want) and np.array_equal(got, want), (bits, kind, path)
-    assert path == ("fused" if dom in (300, 40_000) or kind == "wide" else "subsplit"), path
-    t, m = rhj.join_device(dR, dS)                                   # and the default path on the same inputs
-    assert rhj.stats()["path"] != "subsplit" and np.array_equal(rhj.pairs_to_numpy(t), want)
-
-
 def test_threads_on_the_second_device_when_there_is_one(oracle):
     """HIP's current device is per thread: with the library on device 1, calls from threads that never touched HIP
     must still allocate and launch there (every entry point selects the library's device).  Needs two visible GPUs:
