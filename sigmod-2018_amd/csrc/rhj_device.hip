@@ -153,8 +153,14 @@ int ensure(Buf &b, size_t bytes)
     // first allocation: what is asked for and an eighth; after that at least double — a query plan's joins come in every
     // size and each regrowth is a hipFree + hipMalloc (two device-wide synchronisations): 41 of them in the `small` run
     size_t want = bytes + bytes / 8 + 4096;
-    if (was && want < 2 * was) want = 2 * was;
-    HIP_TRY(hipMalloc(&b.p, want));
+    if (was && was < ((size_t)1 << 30) && want < 2 * was) want = 2 * was;     // (above 1 GiB a regrowth is not a per-query event: no doubling)
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        // the generous size does not fit: what was asked for, exactly (a C4-scale buffer of 16 GB must not fail for its slack)
+        (void)hipGetLastError();
+        b.p = nullptr;
+        want = bytes;
+        HIP_TRY(hipMalloc(&b.p, want));
+    }
     b.cap = want;
     return 0;
 }
@@ -561,11 +567,19 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
                 RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             else
                 RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-            RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);   // returns at once when no unit needs it
             RHJ_STAGE(ST_END);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;                                // written by the join kernel's last workgroup (system-scope stores)
+            if (plan.fused_ok && out && ((const uint64_t *)g.pin)[sizeof(PlanSummary) / 8] != 0) {
+                // some unit's pairs need the index walked again (a probe tuple with more than 16 matches, ...): the host is
+                // waiting on this stream anyway, so the second kernel is launched only now — a launch that returns at once
+                // costs a 0.08 ms join 5 % (the two-pass path, whose joins are milliseconds, always enqueues it)
+                RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                RHJ_STAGE(ST_END);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(g.stream));
+            }
             if (plan.fused_ok && plan.matches == FJ_NO_TOTAL) { fprintf(stderr, "rhj: fused join left no match total (chained scan incomplete)\n"); return -1; }
             if (!plan.fused_ok) { partitioned = true; break; }
             small_done = true;

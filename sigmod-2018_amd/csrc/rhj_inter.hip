@@ -341,6 +341,17 @@ rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS)
         if (rhj_host_null_on_empty()) return nullptr;          // THREADS 1 behaviour
         return make_result(rhj_dev_alloc(8), 0);               // as shipped: an empty head (rhjoin.c:356-359)
     }
+    // A selective join over big inputs would keep a block sized for its INPUT alive for as long as the intermediate result
+    // lives (1.6 GB for a handful of pairs of 100 M-row relations, and every live intermediate of a plan the same): above a
+    // few megabytes, a list that fills less than half of its block moves to a block of its own size (one device copy).
+    if (cap * sizeof(rhj_result_tuple) > ((size_t)8 << 20) && m < cap / 2) {
+        void *exact = rhj_dev_alloc(m * sizeof(rhj_result_tuple));
+        if (exact) {
+            if (hipMemcpyAsync(exact, d, m * sizeof(rhj_result_tuple), hipMemcpyDeviceToDevice, stream()) != hipSuccess) die("RadixHashJoin");
+            rhj_dev_free(d);                                   // (stream-ordered: the copy is queued in front of any reuse)
+            d = exact;
+        }
+    }
     return make_result(d, m);
 }
 

@@ -37,6 +37,9 @@ constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
 constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
 constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
+#ifndef FJ_WIN
+#define FJ_WIN 8                                // entries of a slot compared at once (the array is padded by 8)
+#endif
 constexpr uint32_t FJ_GROUPS = FJ_SPAN / 256;   // a group = the 256 tuples one wave counts in one batch
 constexpr uint32_t FJ_PATCH_CAP = 128;          // irregular tuples per unit whose match rounds are noted in the overflow buffer's tail
 constexpr uint32_t FJ_OVF_ENT = FJ_OVF_CAP - FJ_PATCH_CAP / 2;   // overflow entries a unit may use (the tail holds the patch words)
@@ -147,14 +150,14 @@ template <bool N32> __device__ __forceinline__ uint2 pt_load_key(const rhj_tuple
 template <class IX>
 __device__ __forceinline__ uint32_t fj_window(const IX &X, uint32_t start, uint32_t n, uint32_t tgs)
 {
-    uint32_t e[8];
+    uint32_t e[FJ_WIN];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = X.ent[start + j];
+    for (int j = 0; j < FJ_WIN; ++j) e[j] = X.ent[start + j];
     const uint32_t tg = tgs >> 16;
     uint32_t m = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m |= ((e[j] >> 16) == tg) ? (1u << j) : 0u;
-    return m & ((1u << min(n, 8u)) - 1u);
+    for (int j = 0; j < FJ_WIN; ++j) m |= ((e[j] >> 16) == tg) ? (1u << j) : 0u;
+    return m & ((1u << min(n, (uint32_t)FJ_WIN)) - 1u);
 }
 
 // Per probe tuple: sn = window start | remaining slot length << 16, tm = tag << 16 | hit mask of the
@@ -179,15 +182,15 @@ __device__ __forceinline__ bool fj_round(const IX &X, uint32_t (&sn)[FJ_V], uint
 {
     bool more = false;
 #pragma unroll
-    for (int k = 0; k < FJ_V; ++k) more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u);
+    for (int k = 0; k < FJ_V; ++k) more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > (uint32_t)FJ_WIN);
     while (__ballot(more) != 0) {                     // rare: a slot with more than 8 entries
         more = false;
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
-            if ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u) {
-                sn[k] += 8u - (8u << 16);             // start += 8, length -= 8
+            if ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > (uint32_t)FJ_WIN) {
+                sn[k] += (uint32_t)FJ_WIN - ((uint32_t)FJ_WIN << 16);     // start += window, length -= window
                 tm[k] |= fj_window(X, sn[k] & 0xffffu, sn[k] >> 16, tm[k] & 0xffff0000u);
-                more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > 8u);
+                more = more || ((tm[k] & 0xffu) == 0 && (sn[k] >> 16) > (uint32_t)FJ_WIN);
             }
         }
     }
@@ -205,7 +208,7 @@ __device__ __forceinline__ bool fj_round(const IX &X, uint32_t (&sn)[FJ_V], uint
     }
     bool rest = false;                                // spares the caller a round that finds nothing
 #pragma unroll
-    for (int k = 0; k < FJ_V; ++k) rest = rest || (tm[k] & 0xffu) != 0 || (sn[k] >> 16) > 8u;
+    for (int k = 0; k < FJ_V; ++k) rest = rest || (tm[k] & 0xffu) != 0 || (sn[k] >> 16) > (uint32_t)FJ_WIN;
     last = __ballot(rest) == 0;
     return __ballot(found) != 0;
 }
@@ -532,7 +535,7 @@ __device__ __forceinline__ void fj_run_of(const IX &X, uint64_t key, bool ok, ui
     const uint32_t s = X.slot(h);
     const uint32_t d0 = X.H(s + 1u), n = ok ? X.H(s + 2u) - d0 : 0u;
     const uint32_t tg = X.tag(h);
-    if (n <= 8u) {
+    if (n <= (uint32_t)FJ_WIN) {
         const uint32_t m = fj_window(X, d0, n, tg << 16);
         start = d0 + (m ? (uint32_t)__builtin_ctz(m) : 0u);
         len = (uint32_t)__popc(m);
@@ -1159,6 +1162,10 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
                     const uint64_t v = i == offsetof(PlanSummary, matches) / 8 ? total : src[i];
                     __hip_atomic_store(f.host_summary + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
+                // behind the summary: the units left to k_join_walk (every workgroup is through: the list is complete) — the small
+                // path's host launches that kernel only when there is something to walk
+                const uint32_t nwalk = __hip_atomic_load(f.ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f.host_summary + sizeof(PlanSummary) / 8, (uint64_t)nwalk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
 
     uint4 t[PT_V];
     bool ok[PT_V];
+    bool wide = false;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
@@ -358,6 +359,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : kept);
     __syncthreads();
 
+    // (staging 12-byte tuples as three word arrays, the big win of pass 2, measured +-0 here; the digit bytes as one 8-byte
+    // store per thread +15 %: this kernel sits on the HBM limit)
 #pragma unroll
     for (int k = 0; k < PT_V; ++k)
         if (ok[k]) stage[dstart[dig[k]] + mycnt[dig[k]] + lrank[k]] = t[k];
@@ -366,7 +369,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     uint4 *out = reinterpret_cast<uint4 *>(r.out) + beg;
     Tuple12 *out12 = reinterpret_cast<Tuple12 *>(r.out) + beg;
     uint8_t *dg = r.dig_out + beg;
-    bool wide = false;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t p = k * PT_BLOCK + threadIdx.x;
@@ -515,6 +517,9 @@ __device__ uint64_t g_sr_dbg[256 * 16];           // diagnostics build: phase st
 #else
 #define SR_STAMP(slot) do { } while (0)
 #endif
+#ifndef SR_AOS
+#define SR_AOS 0        // A/B only: 1 = 12-byte tuples staged in 16-byte slots
+#endif
 #ifndef SR_PIPE
 #define SR_PIPE 1       // 1: the next batch's tuple loads are issued before the current batch is written out (0: the round-2 loop, for A/B)
 #endif
@@ -530,7 +535,8 @@ __device__ uint64_t g_sr_dbg[256 * 16];           // diagnostics build: phase st
 //     own run is at most three further on (three independent reads) — it was a chain of ~30 dependent LDS reads per lane;
 //   * 12-byte tuples are staged as three word arrays (the 16-byte slots' scattered stores were 20 % of the kernel's CU cycles
 //     in bank conflicts; a quarter of their bytes was padding);
-//   * the per-wave digit counters are bumped by LDS atomics that return the old value: the rounds no longer wait on each other.
+// (Measured and not kept: the per-wave digit counters bumped by LDS atomics that return the old value instead of read +
+// write by the group's lowest lane: +4 % on C3, +3 % on C4; 16-byte staging slots for 12-byte tuples: +27 % / +10 %.)
 template <bool T12, bool O12>
 __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, RelArgs r1, int shift, int bits, uint32_t search0,
                                                            const PlanSummary *summary)
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             const uint64_t peers = digit_peers(d, ok, bits);
             const uint32_t rank = (uint32_t)__popcll(peers & lt);
             uint32_t old = 0;
-            if (ok && rank == 0) old = atomicAdd(&mycnt[d], (uint32_t)__popcll(peers));   // lowest lane of each digit group (one lane per
+            if (ok && rank == 0) { old = mycnt[d]; mycnt[d] = old + (uint32_t)__popcll(peers); }   // lowest lane of each digit group (one lane per
             const int leader = ok ? __ffsll((unsigned long long)peers) - 1 : 0;           // counter: no ordering between lanes is relied on)
             old = __shfl(old, leader, 64);
             rk[k] = (old + rank) | (d << 16);
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             if (w * (WAVE * SR_V) + k * WAVE + lane < count) {
                 const uint32_t d = rk[k] >> 16;
                 const uint32_t p = dstart[d] + mycnt[d] + (rk[k] & 0xffffu);
-                if (T12) { s_klo[p] = tk[k]; s_khi[p] = th[k]; s_rid[p] = tr[k]; }
+                if (T12 && !SR_AOS) { s_klo[p] = tk[k]; s_khi[p] = th[k]; s_rid[p] = tr[k]; }
                 else stage[p] = make_uint4(tk[k], th[k], tr[k], tw[k]);
             }
         }
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             const uint32_t p = k * PT_BLOCK + threadIdx.x;
             if (p < wcount) {
                 uint4 v;
-                if (T12) v = make_uint4(s_klo[p], s_khi[p], s_rid[p], 0u);
+                if (T12 && !SR_AOS) v = make_uint4(s_klo[p], s_khi[p], s_rid[p], 0u);
                 else v = stage[p];
                 const uint32_t d = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> shift) & mask;
                 if (O12) reinterpret_cast<Tuple12 *>(r.out)[delta[d] + p] = Tuple12{v.x, v.y, v.z};
