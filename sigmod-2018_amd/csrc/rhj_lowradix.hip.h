@@ -226,10 +226,8 @@ __global__ __launch_bounds__(LR_BLOCK, 4) void k_lr_emit(LrArgs a, uint32_t nslo
             const bool ok = w * (WAVE * LR_V) + k * WAVE + lane < total;
             const uint64_t peers = digit_peers(sq[k], ok, (int)a.k_bits);
             const uint32_t rank = (uint32_t)__popcll(peers & lt);
-            uint32_t old = 0;
-            if (ok && rank == 0) { old = mycnt[sq[k]]; mycnt[sq[k]] = old + (uint32_t)__popcll(peers); }
-            const int leader = ok ? __ffsll((unsigned long long)peers) - 1 : 0;
-            old = __shfl(old, leader, 64);
+            const uint32_t old = mycnt[sq[k]];            // the whole group reads its counter, its lowest lane adds the group
+            if (ok && rank == 0) mycnt[sq[k]] = old + (uint32_t)__popcll(peers);
             rk[k] = old + rank;
         }
         __syncthreads();

@@ -520,6 +520,9 @@ __device__ uint64_t g_sr_dbg[256 * 16];           // diagnostics build: phase st
 #ifndef SR_AOS
 #define SR_AOS 0        // A/B only: 1 = 12-byte tuples staged in 16-byte slots
 #endif
+#ifndef SR_NOSHFL
+#define SR_NOSHFL 1
+#endif
 #ifndef SR_PIPE
 #define SR_PIPE 1       // 1: the next batch's tuple loads are issued before the current batch is written out (0: the round-2 loop, for A/B)
 #endif
@@ -653,10 +656,17 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             const uint32_t d = (uint32_t)(key >> shift) & mask;
             const uint64_t peers = digit_peers(d, ok, bits);
             const uint32_t rank = (uint32_t)__popcll(peers & lt);
+#if SR_NOSHFL
+            // the whole digit group reads its counter, then its lowest lane adds the group (a wave's LDS operations complete in
+            // order; one lane per counter writes: no ordering between lanes is relied on) — no shuffle from the leader
+            const uint32_t old = mycnt[d];
+            if (ok && rank == 0) mycnt[d] = old + (uint32_t)__popcll(peers);
+#else
             uint32_t old = 0;
-            if (ok && rank == 0) { old = mycnt[d]; mycnt[d] = old + (uint32_t)__popcll(peers); }   // lowest lane of each digit group (one lane per
-            const int leader = ok ? __ffsll((unsigned long long)peers) - 1 : 0;           // counter: no ordering between lanes is relied on)
+            if (ok && rank == 0) { old = mycnt[d]; mycnt[d] = old + (uint32_t)__popcll(peers); }   // lowest lane of each digit group
+            const int leader = ok ? __ffsll((unsigned long long)peers) - 1 : 0;
             old = __shfl(old, leader, 64);
+#endif
             rk[k] = (old + rank) | (d << 16);
         }
         SR_STAMP(2);
