@@ -41,6 +41,7 @@ WORKLOADS = {
     "c4b13": dict(nR=100_000_000, nS=1_000_000_000, bits=13, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 13 radix bits (experiment)"),
     "c4b15": dict(nR=100_000_000, nS=1_000_000_000, bits=15, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 15 radix bits"),
     "c3b4": dict(nR=100_000_000, nS=100_000_000, bits=4, dist="uniform", name="100Mx100M uniform u64 FK, 4 radix bits = the reference's N_LSB as shipped (not a BASELINE config: buckets of 6 M tuples, tiled path; with --order any the library's own radix)"),
+    "c4b4": dict(nR=100_000_000, nS=1_000_000_000, bits=4, dist="zipf", name="100Mx1B Zipf(0.9) u64 FK, 4 radix bits = the reference's N_LSB as shipped (experiment: low-radix path on skewed keys)"),
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
     "c3b13": dict(nR=100_000_000, nS=100_000_000, bits=13, dist="uniform", name="100Mx100M uniform u64 FK, 13 radix bits (experiment)"),
     "c3b15": dict(nR=100_000_000, nS=100_000_000, bits=15, dist="uniform", name="100Mx100M uniform u64 FK, 15 radix bits (experiment)"),

@@ -809,7 +809,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     ps.lo_bits = r;                                            // pass 1 on exactly the caller's bits: pass 2 reads in canonical order
     uint32_t *words = (uint32_t *)g.lr_words.p;                // word 0: a pass-2 tile / chunk beyond one batch; word 1: k_lr_emit's ticket
     uint8_t *parent_flip = (uint8_t *)(words + 16);            // [2 << r]
-    ps.big_tile = words;
+    ps.big_tile = nullptr;                                     // (a pass-2 tile of several batches is walked batch by batch)
     HIP_TRY(hipMemsetAsync(words, 0, 64, g.stream));
     if (run_partition(ps, T, 2, false, true)) return -1;
     RHJ_STAGE(ST_PLAN);

@@ -199,7 +199,7 @@ def test_foreign_tag_hits_between_matches_on_the_gather_path(rhj, oracle):
     (4, 4_000_000, 2_500_000, 1, 4_000_000, "lowradix"),      # R probes: the bigger side, Poisson matches per tuple
     (8, 12_000_000, 16_000_000, 1, 12_000_000, "lowradix"),
     (5, 2_500_000, 2_500_000, 4, 2_000_000, "lowradix"),      # duplicates on both sides (a few matches per tuple)
-    (4, 2_000_000, 6_000_000, 2, 2_000_000, None),            # Zipf: a pass-2 tile beyond one batch -> refused, tiled path
+    (4, 2_000_000, 6_000_000, 2, 2_000_000, "lowradix"),      # Zipf: the hot key's pass-2 tiles are walked in several batches
     (6, 5_000_000, 5_000_000, 4, 1_500_000, None),            # heavy duplicates: tuples with more than 16 matches -> refused
 ])
 def test_low_radix_path_matches_oracle(rhj, oracle, bits, nR, nS, kind, dom, path):
