@@ -786,7 +786,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
 static int lowradix_sub_bits(int r, uint64_t nR, uint64_t nS)
 {
     const uint64_t nmin = nR < nS ? nR : nS;
-    if (r > PT_MAX_BITS || (nmin >> r) <= 30000) return 0;                // the fused path takes such buckets as they are
+    if (r > PT_MAX_BITS || (nmin >> r) <= 33000) return 0;                // the fused path takes such buckets as they are (its LDS index holds 36 K build tuples)
     int k = 1;
     while (k < PT_MAX_BITS && r + k < MAX_BITS && (nmin >> (r + k)) > 20000) ++k;
     if ((nmin >> (r + k)) > 30000) return 0;                              // even 8 more bits leave the build sides too big
