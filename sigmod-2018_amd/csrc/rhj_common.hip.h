@@ -25,6 +25,11 @@ struct RelArgs {                 // one relation through one partition pass
     uint32_t         group;      // pass-1 tiles per pass-2 tile
     uint32_t         groups;     // pass-2 tiles per pass-1 digit = ceil(tiles1 / group); tiles = bins1 * groups in pass 2
     uint32_t         range_span; // (0: every bucket — the ordinary join)
+    // pass 1 counting pass 2's digits itself (radix bits <= 12): a workgroup walks a STRIP of PT_STRIP pass-1 tiles of one
+    // group and leaves its (pass-1 digit, pass-2 digit) counts, 16 bits each: part[d][strip][digit], strip = group * parts + p
+    uint16_t        *part;
+    uint32_t         parts;      // strips per group = ceil(group / PT_STRIP)
+    uint32_t         pad;
 };
 
 struct Unit {

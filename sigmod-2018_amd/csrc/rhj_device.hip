@@ -84,6 +84,7 @@ struct Ctx {
     int         wide_row_ids = 0;    // 1: never use 12-byte intermediates (env RHJ_WIDE_ROW_IDS)
     int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
     bool        stamps = false;      // env RHJ_STAMPS (diagnostics build): in-kernel phase stamps of the fused kernel, read once at load time
+    int         no_count_in_pass1 = 0;   // 1: pass 2's counts from the digit bytes (k_hist_runs) at every radix width (env RHJ_NO_COUNT_IN_PASS1; A/B)
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 512;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
@@ -93,7 +94,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status, stripR, stripS;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // D2H staging of result pairs (16 MiB each)
@@ -131,6 +132,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
         if ((e = getenv("RHJ_NO_LOWRADIX"))) g.no_lowradix = atoi(e);
+        if ((e = getenv("RHJ_NO_COUNT_IN_PASS1"))) g.no_count_in_pass1 = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
         if ((e = getenv("RHJ_SMALL_TILES"))) { g.small_tiles = (uint32_t)atoi(e); if (g.small_tiles > SM_MAX_TILES) g.small_tiles = SM_MAX_TILES; }
@@ -193,8 +195,12 @@ int ctx_init()
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_local_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    {
+        const void *lp[] = {(const void *)k_local_part<false, true, false>, (const void *)k_local_part<false, true, true>,
+                            (const void *)k_local_part<false, false, true>, (const void *)k_local_part<true, true, false>,
+                            (const void *)k_local_part<true, true, true>,   (const void *)k_local_part<true, false, true>};
+        for (const void *k : lp) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    }
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
@@ -310,7 +316,11 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     uint64_t *ph = (uint64_t *)g.passhp.p, *pp = ph + 2 * 256;
     if (ensure(g.fullhist, (size_t)2 * bins * 4)) return -1;
     RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
-    Buf *digb[2] = {&g.digR, &g.digS}, *runb[2] = {&g.runR, &g.runS}, *cntb[2] = {&g.cntR, &g.cntS};
+    Buf *digb[2] = {&g.digR, &g.digS}, *runb[2] = {&g.runR, &g.runS}, *cntb[2] = {&g.cntR, &g.cntS}, *partb[2] = {&g.stripR, &g.stripS};
+    // pass 1 counts pass 2's digits itself while the (digit, digit) cells fit beside its staging tile (k_local_part); the
+    // digit bytes then serve the low-radix emit only
+    const bool count_in_pass1 = bits <= 12 && !g.no_count_in_pass1;
+    const bool want_dig = !count_in_pass1 || ps.lo_bits != 0;
     RelArgs *ar[2] = {&a0, &a1};
     uint32_t group = 15u * bins1 / 16u;               // a pass-2 tile averages 15/16 of 4096 tuples on uniform keys
     // (the low-radix path replays pass 2 one batch per tile and gives up on a tile beyond 4096 tuples: 7/8 of a batch on
@@ -323,11 +333,14 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         a.tiles1 = a.tiles;
         a.group = group;
         a.groups = (a.tiles1 + group - 1) / group;
-        if (ensure(*digb[i], a.n + 64) || ensure(*runb[i], (size_t)a.tiles1 * (bins1 + 1) * 2 + 64) ||
-            ensure(*cntb[i], (size_t)bins1 * a.groups * bins2 * 4))
+        a.parts = (group + PT_STRIP - 1) / PT_STRIP;
+        if ((want_dig && ensure(*digb[i], a.n + 64)) || ensure(*runb[i], (size_t)a.tiles1 * (bins1 + 1) * 2 + 64) ||
+            ensure(*cntb[i], (size_t)bins1 * a.groups * bins2 * 4) ||
+            (count_in_pass1 && ensure(*partb[i], (size_t)bins * a.groups * a.parts * 2)))
             return -1;
         a.out = ps.tmp[i];
-        a.dig_out = (uint8_t *)digb[i]->p;
+        a.part = count_in_pass1 ? (uint16_t *)partb[i]->p : nullptr;
+        a.dig_out = want_dig ? (uint8_t *)digb[i]->p : nullptr;
         a.runs = (uint16_t *)runb[i]->p;
         a.cnt = (uint32_t *)cntb[i]->p;
     }
@@ -338,7 +351,7 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         RelArgs &b = *br[i];
         b.in = ps.tmp[i];
         b.out = ps.r[i].out;
-        b.dig_in = (const uint8_t *)digb[i]->p;
+        b.dig_in = want_dig ? (const uint8_t *)digb[i]->p : nullptr;
         b.dig_out = nullptr;
         b.tiles = bins1 * b.groups;                   // pass-2 tiles
         if (ar[i]->tiles > max1) max1 = ar[i]->tiles;
@@ -351,18 +364,28 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
     RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
-    if (a0.range_span)
-        RHJ_LAUNCH((k_local_part<true>), dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
-    else
-        RHJ_LAUNCH((k_local_part<false>), dim3(max1, nrel), dim3(PT_BLOCK), scatter_lds_bytes(lo), g.stream, a0, a1, 0, lo, lo, hi, dsum);
-    RHJ_STAGE(ST_SCAN);
     {
+        const uint32_t h2_off = (uint32_t)((scatter_lds_bytes(lo) + 15) & ~(size_t)15);
+        const size_t lds1 = count_in_pass1 ? h2_off + ((size_t)2 << bits) : scatter_lds_bytes(lo);
+        uint32_t strips = 0;
+        for (int i = 0; i < nrel; ++i) strips = ar[i]->groups * ar[i]->parts > strips ? ar[i]->groups * ar[i]->parts : strips;
+        const dim3 grid1(count_in_pass1 ? strips : max1, nrel);
+        const bool ranged = a0.range_span != 0;
+#define RHJ_LP(R, H, D) RHJ_LAUNCH((k_local_part<R, H, D>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, 0, lo, lo, hi, dsum, h2_off)
+        if (ranged) { if (!count_in_pass1) RHJ_LP(true, false, true); else if (want_dig) RHJ_LP(true, true, true); else RHJ_LP(true, true, false); }
+        else        { if (!count_in_pass1) RHJ_LP(false, false, true); else if (want_dig) RHJ_LP(false, true, true); else RHJ_LP(false, true, false); }
+#undef RHJ_LP
+    }
+    RHJ_STAGE(ST_SCAN);
+    HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
+    if (count_in_pass1)
+        RHJ_LAUNCH(k_cnt_from_parts, dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
+    else {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
         RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, nrel), dim3(HR_BLOCK), (size_t)bins2 * 4 * (HR_BLOCK / WAVE), g.stream,
-                   b0, b1, hi, ps.big_tile);
+                   b0, b1, hi);
+        RHJ_LAUNCH(k_full_from_cnt, dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
     }
-    HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
-    RHJ_LAUNCH(k_full_from_cnt, dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
     {
         uint32_t chunks = (max2 + 15) / 16;
         if (chunks > 512) chunks = 512;
@@ -1289,7 +1312,7 @@ void rhj_release(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);

@@ -283,9 +283,19 @@ __global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, in
 // RANGED: a sharded join (rhj_join_device_range) — only the tuples whose bucket, the low shift + bits + next_bits key bits, lies
 // in the rank's range go on; the tile shrinks in place, its run table says by how much, and everything downstream reads runs.
 // Compiled apart: the test in the ordinary kernel cost it 27 % on 100M x 1B (r03: 5.7 -> 7.3 ms) although it never fires there.
-template <bool RANGED>
+// H2: the workgroup walks a strip of PT_STRIP tiles and counts (this pass' digit, the next pass' digit) in LDS — 2^(bits +
+// next_bits) 16-bit cells, at most 8 KiB — one LDS atomic a tuple, which this kernel has room for (+0.5 %); the strip's
+// counts go out once (RelArgs::part) and k_cnt_from_parts sums a group's strips into pass 2's count table.  Without it
+// (radix bits 13..15: the cells would cost the second resident workgroup) k_hist_runs counts from the digit bytes, which
+// cost 0.15 ms on 100M + 100M tuples — as many LDS atomics, but in a kernel that does nothing else.
+// DIG: the next pass' digit of every tuple as one byte (k_hist_runs and the low-radix emit read them).
+#ifndef PT_STRIP_N
+#define PT_STRIP_N 4
+#endif
+constexpr uint32_t PT_STRIP = PT_STRIP_N;           // (16-bit cells: a strip may hold at most 15 tiles)
+template <bool RANGED, bool H2, bool DIG>
 __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
-                                                         PlanSummary *summary)
+                                                         PlanSummary *summary, uint32_t h2_off)
 {
     const bool T12 = summary->wide_row_ids == 0;          // 12-byte intermediates (workgroup-uniform)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -294,21 +304,30 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     uint32_t *dstart = wcnt + PT_WAVES * bins;                                 // [bins]
     uint64_t *sm = reinterpret_cast<uint64_t *>(dstart + 2 * bins);            // scan scratch
+    uint32_t *h2 = reinterpret_cast<uint32_t *>(smem + h2_off);                // H2: [2^(bits + next_bits) / 2], two cells a word
 
     const RelArgs &r = blockIdx.y ? r1 : r0;
-    const uint32_t tile = blockIdx.x;
-    if (tile >= r.tiles) return;
+    uint32_t tile = blockIdx.x, tile_end = tile + 1;
+    if (H2) {
+        const uint32_t strip = blockIdx.x, j = strip / r.parts, p = strip - j * r.parts;
+        if (j >= r.groups) return;
+        tile = j * r.group + p * PT_STRIP;
+        tile_end = min(min(tile + PT_STRIP, (j + 1) * r.group), r.tiles);
+        for (uint32_t i = threadIdx.x; i < (1u << (bits + next_bits - 1)); i += PT_BLOCK) h2[i] = 0;
+    } else if (tile >= r.tiles) return;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    const uint64_t beg = (uint64_t)tile * PT_TILE;
-    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
-    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+    bool wide = false;
 
+    for (; tile < tile_end; ++tile) {                 // (one tile unless H2; the barriers of a round keep the rounds apart.
+    const uint64_t beg = (uint64_t)tile * PT_TILE;    //  The strip costs this kernel 5 %: a tile's stores now drain in front of
+    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);   // the next tile's barrier instead of behind the
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;        // workgroup's end; reading the next tile before
+                                                                          // the write-out made it 10 %.)
     for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
 
     uint4 t[PT_V];
     bool ok[PT_V];
-    bool wide = false;
 #pragma unroll
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
@@ -325,6 +344,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
         if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << (shift + bits + next_bits)) - 1u)) - r.range_lo) < r.range_span;
         dig[k] = d;
+        if (H2 && ok[k]) {
+            const uint32_t cell = (d << next_bits) | ((uint32_t)(key >> next_shift) & ((1u << next_bits) - 1u));
+            atomicAdd(&h2[cell >> 1], 1u << ((cell & 1u) * 16u));
+        }
         uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
         for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
             const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
@@ -376,10 +399,20 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
             const uint4 v = stage[p];
             if (T12) { out12[p] = Tuple12{v.x, v.y, v.z}; wide = wide || v.w != 0; }
             else out[p] = v;
-            dg[p] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
+            if (DIG) dg[p] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
         }
     }
+    }
     if (T12 && __ballot(wide) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->row_id_overflow, 1u);
+    if (H2) {
+        __syncthreads();
+        const uint32_t strips = r.groups * r.parts, half = 1u << (next_bits - 1);     // words a digit row
+        uint32_t *dst = reinterpret_cast<uint32_t *>(r.part);
+        for (uint32_t i = threadIdx.x; i < (1u << (bits + next_bits - 1)); i += PT_BLOCK) {
+            const uint32_t d = i >> (next_bits - 1), hw = i & (half - 1u);
+            dst[((size_t)d * strips + blockIdx.x) * half + hw] = h2[i];
+        }
+    }
 }
 // pass-2 tile -> its runs: thread i < group describes run i (two coalesced reads of the transposed table)
 __device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint32_t i, uint32_t &phys, uint32_t &len)
@@ -399,7 +432,7 @@ __device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint
 // four digit bytes a lane), eight such loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
 // chain of dependent latencies: 6 us per tile, 0.32 ms for 100M + 100M tuples.)
 constexpr int HR_BLOCK = 256;
-__global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits, uint32_t *big_tile)
+__global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, int bits)
 {
     extern __shared__ uint32_t lds_u32[];
     const RelArgs &r = blockIdx.y ? r1 : r0;
@@ -409,11 +442,9 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
     const uint32_t stride = gridDim.x * (HR_BLOCK / WAVE);
     for (uint32_t tile2 = blockIdx.x * (HR_BLOCK / WAVE) + w; tile2 < r.tiles; tile2 += stride) {
         for (uint32_t b = lane; b < bins; b += WAVE) h[b] = 0;
-        uint32_t tile_total = 0;
         for (uint32_t c0 = 0; c0 < r.group; c0 += WAVE) {
             uint32_t phys, len;
             pt_run_of(r, tile2, c0 + lane, phys, len);
-            tile_total += len;
             const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
 #ifdef HR_BYTE_LOADS      // the first form: one run per wave load, a byte per lane (kept for A/B)
             for (uint32_t q0 = 0; q0 < nrun; q0 += 16) {
@@ -466,11 +497,6 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
         }
         uint32_t *row = r.cnt + (size_t)tile2 * bins;
         for (uint32_t b = lane; b < bins; b += WAVE) row[b] = h[b];
-        if (big_tile) {                               // (low-radix path: it replays pass 2 one batch per tile)
-            uint32_t all;
-            wave_excl_scan_u32(tile_total, &all);
-            if (lane == 0 && all > 4096u) atomicOr(big_tile, 1u);
-        }
     }
 }
 
@@ -490,6 +516,40 @@ __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, 
     const uint32_t *base = r.cnt + (size_t)d * r.groups * bins + b;
 #pragma unroll 4
     for (uint32_t j = j0 + row; j < j1; j += rows) s += base[(size_t)j * bins];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < bins) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < rows; ++q) t += part[q * bins + threadIdx.x];
+        if (t) atomicAdd(&full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)], t);
+    }
+}
+
+// the same when pass 1 counted (k_local_part<., true, .>): a group's strips summed give pass 2's count row of tile (d, group),
+// written here, and the rows' column sums the bucket histogram as above
+__global__ __launch_bounds__(1024) void k_cnt_from_parts(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
+{
+    __shared__ uint32_t part[1024];
+    const RelArgs &r = blockIdx.y ? r1 : r0;
+    const uint32_t bins = 1u << bits, d = blockIdx.x;
+    const uint32_t b = threadIdx.x & (bins - 1u), row = threadIdx.x >> bits, rows = 1024u >> bits;
+    const uint32_t per = (r.groups + gridDim.z - 1u) / gridDim.z;
+    const uint32_t j0 = min(blockIdx.z * per, r.groups), j1 = min(j0 + per, r.groups);
+    uint32_t s = 0;
+    const uint16_t *src = r.part + (size_t)d * r.groups * r.parts * bins + b;
+    uint32_t *dst = r.cnt + (size_t)d * r.groups * bins + b;
+    for (uint32_t j = j0 + row; j < j1; j += rows) {
+        uint32_t v = 0, p = 0;
+        const uint16_t *sj = src + (size_t)j * r.parts * bins;
+        for (; p + 4 <= r.parts; p += 4) {            // (four loads in flight: one at a time this kernel took 40 us)
+            const uint32_t a0 = sj[(size_t)p * bins], a1 = sj[(size_t)(p + 1) * bins], a2 = sj[(size_t)(p + 2) * bins],
+                           a3 = sj[(size_t)(p + 3) * bins];
+            v += a0 + a1 + a2 + a3;
+        }
+        for (; p < r.parts; ++p) v += sj[(size_t)p * bins];
+        dst[(size_t)j * bins] = v;
+        s += v;
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < bins) {
