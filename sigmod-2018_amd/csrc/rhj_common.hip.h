@@ -29,7 +29,10 @@ struct RelArgs {                 // one relation through one partition pass
     // group and leaves its (pass-1 digit, pass-2 digit) counts, 16 bits each: part[d][strip][digit], strip = group * parts + p
     uint16_t        *part;
     uint32_t         parts;      // strips per group = ceil(group / PT_STRIP)
-    uint32_t         pad;
+    uint32_t         per;        // groups per scan slice = ceil(groups / FH_SLICES)
+    // pass 2's start offsets come in two parts: cnt[tile (d, j)][digit] = the tuples of (d, digit) in groups of j's slice in
+    // front of j, sbase[d][slice][digit] = where that slice starts in the output (bucket start + the slices in front of it)
+    uint32_t        *sbase;
 };
 
 struct Unit {
@@ -175,6 +178,37 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *total,
     return sm[w] + x - v;
 }
 
+// N values a thread through the same three barriers (the plan scans five: one after the other they cost it 15 barriers)
+template <int NT, int N>
+__device__ __forceinline__ void block_excl_scan_n(const uint64_t (&v)[N], uint64_t (&excl)[N], uint64_t (&total)[N],
+                                                  uint64_t *sm /*N * (NT/64+1)*/)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = wave_incl_scan_u64(v[i]);
+    __syncthreads();                       // sm reuse across calls
+    if (lane == 63)
+#pragma unroll
+        for (int i = 0; i < N; ++i) sm[i * (NT / 64 + 1) + w] = x[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {                // one wave scans the wave totals
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t *s = sm + i * (NT / 64 + 1);
+            const uint64_t t = threadIdx.x < NT / 64 ? s[threadIdx.x] : 0;
+            const uint64_t y = wave_incl_scan_u64(t);
+            if (threadIdx.x < NT / 64) s[threadIdx.x] = y - t;
+            if (threadIdx.x == NT / 64 - 1) s[NT / 64] = y;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        total[i] = sm[i * (NT / 64 + 1) + NT / 64];
+        excl[i] = sm[i * (NT / 64 + 1) + w] + x[i] - v[i];
+    }
+}
 
 // Exclusive scan of n u64 counts in three launches (n up to ~1M per 1024 block sums):
 //   k_offsets_local  per 1024-element block: exclusive scan in place -> base, block total

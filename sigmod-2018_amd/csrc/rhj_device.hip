@@ -85,6 +85,7 @@ struct Ctx {
     int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
     bool        stamps = false;      // env RHJ_STAMPS (diagnostics build): in-kernel phase stamps of the fused kernel, read once at load time
     int         no_count_in_pass1 = 0;   // 1: pass 2's counts from the digit bytes (k_hist_runs) at every radix width (env RHJ_NO_COUNT_IN_PASS1; A/B)
+    int         seen_wide = 0;       // a join of this process needed 16-byte intermediates: launch those kernels from now on
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 512;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
@@ -94,7 +95,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status, stripR, stripS;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status, stripR, stripS, slice_tot, sbase;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // D2H staging of result pairs (16 MiB each)
@@ -210,6 +211,7 @@ int ctx_init()
 }
 
 struct PartState {
+    bool     launch_wide = false;    // the 16-byte kernels of the two-pass partition were launched (else only the 12-byte ones)
     RelArgs  p2[2];          // two-pass partition: the relations as pass 2 saw them (runs, digit bytes, scanned tile counts) —
                              // the low-radix path replays pass 2's order when it emits (rhj_lowradix.hip.h)
     int      lo_bits = 0;    // two-pass partition: digit bits of pass 1 (0: half of the radix); the low-radix path passes the caller's radix
@@ -297,7 +299,6 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     RelArgs none = RelArgs{};
     for (int i = 0; i < nrel; ++i) ps.r[i].tiles = tiles_for(ps.r[i].n);
     if (ensure(g.summary, sizeof(PlanSummary))) return -1;
-    HIP_TRY(hipMemsetAsync(&((PlanSummary *)g.summary.p)->wide_row_ids, 0, 8, g.stream));    // wide_row_ids, row_id_overflow
     if (ensure(g.cntR, (size_t)ps.r[0].tiles * 256 * 4)) return -1;
     ps.r[0].cnt = (uint32_t *)g.cntR.p;
     if (nrel > 1) {
@@ -306,15 +307,16 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     }
     if (bits <= PT_MAX_BITS && !ps.lo_bits) {
         // one pass: no 12-byte intermediates and nothing that checks the row ids, so everything downstream stays wide
+        HIP_TRY(hipMemsetAsync(&((PlanSummary *)g.summary.p)->wide_row_ids, 0, 8, g.stream));    // wide_row_ids, row_id_overflow
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&((PlanSummary *)g.summary.p)->wide_row_ids, 1, 1, g.stream));
+        ps.launch_wide = true;
         return partition_pass(ps.r[0], nrel > 1 ? ps.r[1] : none, nrel, bits, ps.hist, ps.psum, ps.plan, &ps.plan_done);
     }
 
     // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
     const int lo = ps.lo_bits ? ps.lo_bits : bits / 2, hi = bits - lo;
     const uint32_t bins1 = 1u << lo, bins2 = 1u << hi;
-    uint64_t *ph = (uint64_t *)g.passhp.p, *pp = ph + 2 * 256;
-    if (ensure(g.fullhist, (size_t)2 * bins * 4)) return -1;
+    if (ensure(g.slice_tot, (size_t)2 * bins * FH_SLICES * 4) || ensure(g.sbase, (size_t)2 * bins * FH_SLICES * 4)) return -1;
     RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
     Buf *digb[2] = {&g.digR, &g.digS}, *runb[2] = {&g.runR, &g.runS}, *cntb[2] = {&g.cntR, &g.cntS}, *partb[2] = {&g.stripR, &g.stripS};
     // pass 1 counts pass 2's digits itself while the (digit, digit) cells fit beside its staging tile (k_local_part); the
@@ -334,6 +336,8 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         a.group = group;
         a.groups = (a.tiles1 + group - 1) / group;
         a.parts = (group + PT_STRIP - 1) / PT_STRIP;
+        a.per = (a.groups + FH_SLICES - 1) / FH_SLICES;
+        a.sbase = (uint32_t *)g.sbase.p + (size_t)i * bins * FH_SLICES;
         if ((want_dig && ensure(*digb[i], a.n + 64)) || ensure(*runb[i], (size_t)a.tiles1 * (bins1 + 1) * 2 + 64) ||
             ensure(*cntb[i], (size_t)bins1 * a.groups * bins2 * 4) ||
             (count_in_pass1 && ensure(*partb[i], (size_t)bins * a.groups * a.parts * 2)))
@@ -358,12 +362,15 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         if (b.tiles > max2) max2 = b.tiles;
     }
     // 12-byte intermediates when the row ids fit 32 bits: a sample decides on the device and the pass
-    // kernels read the decision there (no host round trip; pass 2 is compiled once per format and the
-    // instantiation not chosen returns at once)
+    // kernels read the decision there (no host round trip; pass 2 is compiled once per format).  The host
+    // launches the 12-byte kernels alone until a join of this process turned out to need the 16-byte ones
+    // (g.seen_wide): the sample then reports a wide input as an overflow and the caller runs again wide.
+    const bool launch_narrow = !force_wide;
+    ps.launch_wide = force_wide || g.seen_wide;
     if (ensure(g.summary, sizeof(PlanSummary))) return -1;
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
     RHJ_STAGE(ST_HIST);
-    RHJ_LAUNCH(k_rowid_sample, dim3(8), dim3(256), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, dsum);
+    RHJ_LAUNCH(k_rowid_sample, dim3(1), dim3(1024), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, ps.launch_wide ? 0 : 1, dsum);
     {
         const uint32_t h2_off = (uint32_t)((scatter_lds_bytes(lo) + 15) & ~(size_t)15);
         const size_t lds1 = count_in_pass1 ? h2_off + ((size_t)2 << bits) : scatter_lds_bytes(lo);
@@ -377,27 +384,18 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
 #undef RHJ_LP
     }
     RHJ_STAGE(ST_SCAN);
-    HIP_TRY(hipMemsetAsync(g.fullhist.p, 0, (size_t)2 * bins * 4, g.stream));
     if (count_in_pass1)
-        RHJ_LAUNCH(k_cnt_from_parts, dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
+        RHJ_LAUNCH((k_group_scan<true>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p);
     else {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
         RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, nrel), dim3(HR_BLOCK), (size_t)bins2 * 4 * (HR_BLOCK / WAVE), g.stream,
                    b0, b1, hi);
-        RHJ_LAUNCH(k_full_from_cnt, dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, lo, hi, (uint32_t *)g.fullhist.p);
+        RHJ_LAUNCH((k_group_scan<false>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p);
     }
-    {
-        uint32_t chunks = (max2 + 15) / 16;
-        if (chunks > 512) chunks = 512;
-        if (chunks < 1) chunks = 1;
-        if (ensure(g.chunk, (size_t)2 * chunks * bins2 * 8)) return -1;
-        RHJ_LAUNCH(k_scan_chunks, dim3((bins2 + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, b0, b1, hi, chunks,
-                   (uint64_t *)g.chunk.p);
-        RHJ_LAUNCH(k_scan_bins, dim3(bins2, nrel), dim3(WAVE), 0, g.stream, hi, chunks, (uint64_t *)g.chunk.p, ph);
-        RHJ_LAUNCH(k_scan_psum, dim3(nrel), dim3(1024), 0, g.stream, hi, (const uint64_t *)ph, pp);
-        RHJ_LAUNCH(k_scan_apply, dim3((bins2 + 255) / 256, chunks, nrel), dim3(256), 0, g.stream, b0, b1, hi, chunks,
-                   (const uint64_t *)g.chunk.p, (const uint64_t *)pp);
-    }
+#define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), 0, g.stream, lo, hi, (const uint32_t *)g.slice_tot.p, \
+                            (uint32_t *)g.sbase.p, ps.hist, ps.psum)
+    if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else RHJ_BP(0);
+#undef RHJ_BP
     RHJ_STAGE(ST_SCATTER);
     uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search
     while (search0 * 2 <= group) search0 *= 2;
@@ -407,17 +405,16 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         if (per_cu < 1) per_cu = 1;
         const uint32_t sgrid = (uint32_t)g.cus * per_cu;
         const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;     // a multiple of the 8 XCDs
-        if (final12)
+        if (launch_narrow && final12)
             RHJ_LAUNCH((k_scatter_runs<true, true>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
                        lo, hi, search0, (const PlanSummary *)dsum);
-        else
+        else if (launch_narrow)
             RHJ_LAUNCH((k_scatter_runs<true, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
                        lo, hi, search0, (const PlanSummary *)dsum);
-        RHJ_LAUNCH((k_scatter_runs<false, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
-                   lo, hi, search0, (const PlanSummary *)dsum);
+        if (ps.launch_wide)
+            RHJ_LAUNCH((k_scatter_runs<false, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
+                       lo, hi, search0, (const PlanSummary *)dsum);
     }
-    RHJ_LAUNCH(k_full_psum, dim3(nrel), dim3(1024), 0, g.stream, bits, (const uint32_t *)g.fullhist.p, ps.hist,
-                       ps.psum);
     ps.p2[0] = b0; ps.p2[1] = b1;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -505,7 +502,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk;
-    pa.parent_mask = 0; pa.parent_flip = nullptr;
+    pa.parent_mask = 0; pa.parent_flip = nullptr; pa.zero = nullptr; pa.zero_words = 0;
     // probe tuples per fused unit: whole buckets when there are plenty of them, smaller spans (each unit
     // rebuilds its bucket's index) when a low radix would otherwise leave most CUs idle
     uint32_t fused_span = FJ_SPAN;
@@ -629,10 +626,17 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         if (use_ctx_out) { out = nullptr; out_capacity = 0; }
     }
 
+    const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;      // fused path: the host-side bound on the unit count
     if (!partitioned) {
         if (run_partition(ps, bits, 2, force_wide, want_fused && !force_wide)) return -1;
         RHJ_STAGE(ST_PLAN);
+        if (want_fused) {                             // the plan clears the fused kernel's ticket and status words
+            if (ensure(g.status, (unit_bound + 1) * 8 + 64)) return -1;
+            pa.zero = (uint32_t *)g.status.p; pa.zero_words = (uint32_t)(((unit_bound + 1) * 8 + 64) / 4);
+        }
         if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+        else if (want_fused) HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
+        pa.zero = nullptr; pa.zero_words = 0;
     } else {
         RHJ_STAGE(ST_HIST);
         RHJ_STAGE(ST_SCAN);
@@ -647,7 +651,6 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         // without waiting for the plan: the grid is the host-side upper bound on the unit count, the
         // LDS allocation the maximum, and the kernel itself returns when the plan found a bucket that
         // does not fit LDS (then the tiled path below takes over).  One host sync per join.
-        const uint64_t unit_bound = (uint64_t)bins + (nR + nS) / fused_span + 2;
         if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
             ensure(g.status, (unit_bound + 1) * 8 + 64) ||
             ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
@@ -680,22 +683,25 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         for (int attempt = 0; attempt < 2; ++attempt) {
             ja.out = out; ja.out_capacity = out ? out_capacity : 0;
             fa.j = ja;
-            HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
+            if (attempt) HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));   // (first: cleared by the plan)
             // workgroups are persistent (ticket loop) and the LDS request leaves room for one per CU
             const unsigned fgrid = (unsigned)(unit_bound < (uint64_t)g.cus ? unit_bound : (uint64_t)g.cus);
             // the resident variant only when an average bucket could fit beside the index (~7.4 K tuples)
-            // Both stash widths are launched; the one that does not match the partition's row-id decision
-            // (summary->wide_row_ids, known only on the device) returns at once.
-            // (One-pass partitions and forced-wide runs are wide by construction: the host knows, one launch.)
+            // The stash width follows the partition's row-id decision (summary->wide_row_ids, known only on the device):
+            // the instantiation that does not match returns at once, and the 16-byte one is launched only when the
+            // partition's 16-byte kernels were (one-pass partitions, forced-wide runs, a process that has seen wide row ids).
             const bool maybe_narrow = bits > PT_MAX_BITS && !force_wide;
+            const bool maybe_wide = !maybe_narrow || ps.launch_wide;
             if (nmin / bins <= 7000 && !g.no_resident) {
                 if (maybe_narrow)
                     RHJ_LAUNCH((k_join_fused<true, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-                RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                if (maybe_wide)
+                    RHJ_LAUNCH((k_join_fused<true, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             } else {
                 if (maybe_narrow)
                     RHJ_LAUNCH((k_join_fused<false, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
-                RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                if (maybe_wide)
+                    RHJ_LAUNCH((k_join_fused<false, false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
             }
             RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);   // returns at once when no unit needs it
             RHJ_STAGE(ST_END);
@@ -703,6 +709,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;
+            if (plan.row_id_overflow) { *overflow = true; return 0; }     // (also: wide row ids met the 12-byte kernels alone)
             if (plan.fused_ok && plan.matches == FJ_NO_TOTAL && !g.ablate) { fprintf(stderr, "rhj: fused join left no match total (chained scan incomplete)\n"); return -1; }
             if (!plan.fused_ok) {
                 // a bucket needs the tiled path, which reads 16-byte tuples: partition again wide if this one was narrow
@@ -857,7 +864,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     pa.units = (Unit *)g.units.p; pa.build_units = (Unit *)g.bunits.p; pa.lds_buckets = (uint32_t *)g.ldsb.p;
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = LDS_BUDGET / 4 / 4 * 4; pa.build_chunk = build_chunk; pa.span_lds = FJ_SPAN;
-    pa.parent_mask = (1u << r) - 1u; pa.parent_flip = parent_flip;
+    pa.parent_mask = (1u << r) - 1u; pa.parent_flip = parent_flip; pa.zero = nullptr; pa.zero_words = 0;
     RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, T);
 
     JoinArgs ja;
@@ -1009,6 +1016,7 @@ static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *
         }
     }
     int rc = join_device_once(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, g.wide_row_ids != 0, &overflow);
+    if (rc >= 0 && overflow) g.seen_wide = 1;
     if (rc >= 0 && overflow)
         rc = join_device_once(dR, nR, dS, nS, out, out_capacity, use_ctx_out, ctx_out, matches, true, &overflow);
     return rc;
@@ -1238,6 +1246,7 @@ int rhj_partition_device(const rhj_tuple *d_in, uint64_t n, rhj_tuple *d_out, ui
         HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         if (!hs->row_id_overflow) break;                      // else: a row id above 2^32 - 1 met a 12-byte intermediate
+        g.seen_wide = 1;
     }
     for (uint32_t b = 0; b < bins; ++b) {
         if (h_hist) h_hist[b] = hh[b];
@@ -1312,7 +1321,7 @@ void rhj_release(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.slice_tot, &g.sbase, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);

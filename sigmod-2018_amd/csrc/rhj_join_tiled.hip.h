@@ -27,6 +27,8 @@ struct PlanArgs {
     uint32_t        span_lds;       // probe tuples per unit in LDS-table buckets (PR_UNIT on the tiled path)
     uint32_t        parent_mask;    // low-radix path (see JoinArgs): the side choice of the caller's bucket
     const uint8_t  *parent_flip;
+    uint32_t       *zero;           // words the plan clears for the kernels behind it (the fused join's ticket and status words), or null
+    uint32_t        zero_words;
 };
 
 constexpr uint32_t T32_PAD = 8;         // replica of the first 8 entries behind every 32-bit table
@@ -38,43 +40,75 @@ __device__ __forceinline__ uint32_t lds_slots_for(uint64_t bc, uint32_t max_slot
     return min(max(s, 64u), max_slots);
 }
 
-__device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t *sm /*1024 / 64 + 1*/, unsigned long long *red /*2*/)
+__device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t *sm /*5 * (1024 / 64 + 1)*/, unsigned long long *red /*2*/)
 {
     const uint32_t bins = 1u << bits;
     const uint32_t per = (bins + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, bins);
     if (threadIdx.x < 2) red[threadIdx.x] = 0;
+    if (a.zero)
+        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero[i] = 0;
 
     uint64_t nu = 0, nbu = 0, slots64 = 0, nlds = 0, slots32 = 0;
     uint32_t max_build = 0, max_slots = 0;
-    for (uint32_t b = b0; b < b1; ++b) {
-        const uint64_t cR = a.histR[b], cS = a.histS[b];
+    // (a thread's bucket sizes are read eight buckets at a time: one bucket after the other the loop waited for every pair)
+    constexpr uint32_t PB = 8;
+    for (uint32_t bb = b0; bb < b1; bb += PB) {
+      uint64_t cRv[PB], cSv[PB];
+#pragma unroll
+      for (uint32_t i = 0; i < PB; ++i) {
+          const bool in = bb + i < b1;
+          cRv[i] = in ? a.histR[bb + i] : 0;
+          cSv[i] = in ? a.histS[bb + i] : 0;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < PB; ++i) {
+        const uint32_t b = bb + i;
+        const uint64_t cR = cRv[i], cS = cSv[i];
         if (cR == 0 || cS == 0) continue;
         const bool flip = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;   // rhjoin.c:86 (>=)
         const uint64_t pc = flip ? cS : cR, bc = flip ? cR : cS;
         const uint64_t span = bc <= a.lds_cap ? a.span_lds : PR_UNIT;
-        nu += (pc + span - 1) / span;
+        nu += ((uint32_t)pc - 1u) / (uint32_t)span + 1u;                   // (bucket sizes are in [1, 2^32): 32-bit divisions)
         max_build = max(max_build, (uint32_t)min(bc, (uint64_t)0xffffffffu));
         if (bc <= a.lds_cap) {
             const uint32_t s = lds_slots_for(bc, a.lds_max_slots);
             nlds += 1; slots32 += s + T32_PAD;
             max_slots = max(max_slots, s);
         } else {
-            nbu += (bc + a.build_chunk - 1) / a.build_chunk;
+            nbu += ((uint32_t)bc - 1u) / a.build_chunk + 1u;
             slots64 += 1ull << (64 - __clzll((unsigned long long)(2 * bc - 1)));   // pow2 >= 2*bc
         }
+      }
     }
-    uint64_t tot_u, tot_b, tot_s64, tot_l, tot_s32;
-    uint64_t ubase = block_excl_scan<1024>(nu, &tot_u, sm);
-    uint64_t bbase = block_excl_scan<1024>(nbu, &tot_b, sm);
-    uint64_t s64base = block_excl_scan<1024>(slots64, &tot_s64, sm);
-    uint64_t lbase = block_excl_scan<1024>(nlds, &tot_l, sm);
-    uint64_t s32base = block_excl_scan<1024>(slots32, &tot_s32, sm);
-    atomicMax(&red[0], (unsigned long long)max_build);
-    atomicMax(&red[1], (unsigned long long)max_slots);
+    const uint64_t mine5[5] = {nu, nbu, slots64, nlds, slots32};
+    uint64_t ex5[5], tot5[5];
+    block_excl_scan_n<1024, 5>(mine5, ex5, tot5, sm);
+    uint64_t ubase = ex5[0], bbase = ex5[1], s64base = ex5[2], lbase = ex5[3], s32base = ex5[4];
+    const uint64_t tot_u = tot5[0], tot_b = tot5[1], tot_s64 = tot5[2], tot_l = tot5[3], tot_s32 = tot5[4];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {                    // (one LDS atomic a wave: 1024 on one address took 10 us)
+        max_build = max(max_build, (uint32_t)__shfl_xor((int)max_build, o, 64));
+        max_slots = max(max_slots, (uint32_t)__shfl_xor((int)max_slots, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&red[0], (unsigned long long)max_build);
+        atomicMax(&red[1], (unsigned long long)max_slots);
+    }
 
-    for (uint32_t b = b0; b < b1; ++b) {
-        const uint64_t cR = a.histR[b], cS = a.histS[b];
+    for (uint32_t bb = b0; bb < b1; bb += PB) {
+      uint64_t cRv[PB], cSv[PB];
+#pragma unroll
+      for (uint32_t i = 0; i < PB; ++i) {
+          const bool in = bb + i < b1;
+          cRv[i] = in ? a.histR[bb + i] : 0;
+          cSv[i] = in ? a.histS[bb + i] : 0;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < PB; ++i) {
+        const uint32_t b = bb + i;
+        if (b >= b1) break;
+        const uint64_t cR = cRv[i], cS = cSv[i];
         BucketMeta m = {0, 0, 0};
         if (cR != 0 && cS != 0) {
             const bool flip = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;
@@ -103,6 +137,7 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
             }
         }
         a.meta[b] = m;
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -117,7 +152,7 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
 
 __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
 {
-    __shared__ uint64_t sm[1024 / 64 + 1];
+    __shared__ uint64_t sm[5 * (1024 / 64 + 1)];
     __shared__ unsigned long long red[2];
     plan_body(a, bits, sm, red);
 }
@@ -129,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a, int bits)
 constexpr uint32_t SMALL_TILES = 1024;
 __global__ __launch_bounds__(1024) void k_small_scan_plan(RelArgs r0, RelArgs r1, int bits, uint64_t *hist, uint64_t *psum, PlanArgs a)
 {
-    __shared__ uint64_t sm[1024 / 64 + 1];
+    __shared__ uint64_t sm[5 * (1024 / 64 + 1)];
     __shared__ unsigned long long red[2];
     __shared__ uint32_t part[1024];
     __shared__ uint32_t base_sh[2][256];

@@ -83,9 +83,9 @@ __device__ __forceinline__ void lr_stream(const LrArgs &a, const LrChunk &c, uin
 {
     const uint32_t bins = 1u << a.k_bits;
     const uint32_t b = slot / a.slots_per_bucket, chunk = slot % a.slots_per_bucket;
-    first = c.r->cnt[(size_t)c.tile2 * bins + s];
+    first = pt_start(*c.r, c.tile2, s, bins);
     uint32_t end;
-    if (chunk + 1u < c.r->groups) end = c.r->cnt[(size_t)(c.tile2 + 1u) * bins + s];
+    if (chunk + 1u < c.r->groups) end = pt_start(*c.r, c.tile2 + 1u, s, bins);
     else {                                           // the bucket's last chunk: up to the end of sub-bucket (s, b)
         const uint32_t sub = (s << a.r_bits) | b;
         end = (uint32_t)((c.flip ? a.j.psumS[sub] : a.j.psumR[sub]) + (c.flip ? a.j.histS[sub] : a.j.histR[sub]));

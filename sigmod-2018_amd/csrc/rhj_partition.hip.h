@@ -257,16 +257,24 @@ __global__ __launch_bounds__(PT_BLOCK) void k_scatter_lds(RelArgs r0, RelArgs r1
 // runs the join again with 16-byte intermediates).
 struct __attribute__((aligned(4))) Tuple12 { uint32_t klo, khi, rid; };
 
-// first and last 2048 row ids of both relations -> summary->wide_row_ids (the host cleared both words)
-__global__ __launch_bounds__(256) void k_rowid_sample(RelArgs r0, RelArgs r1, int nrel, int force_wide, PlanSummary *summary)
+// first and last 2048 row ids of both relations -> summary->wide_row_ids, and summary->row_id_overflow cleared (one
+// workgroup writes both words: no memset in front).  expect_narrow: the host launched the 12-byte kernels only — it does so
+// until a join of this process needed the 16-byte ones — so a wide sample is reported as an overflow, which makes the
+// caller run the join again with the 16-byte kernels.
+__global__ __launch_bounds__(1024) void k_rowid_sample(RelArgs r0, RelArgs r1, int nrel, int force_wide, int expect_narrow,
+                                                       PlanSummary *summary)
 {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;       // 8 workgroups: 2048 positions from each end
     uint32_t mine = force_wide ? 1u : 0u;
     for (int rel = 0; rel < nrel; ++rel) {
         const RelArgs &r = rel ? r1 : r0;
-        if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32) | (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
+        for (uint32_t j = threadIdx.x; j < 2048u; j += 1024u)
+            if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32) | (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
     }
-    if (__ballot(mine != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(&summary->wide_row_ids, 1u);
+    const int wide = __syncthreads_or(mine != 0);
+    if (threadIdx.x == 0) {
+        summary->wide_row_ids = wide ? 1u : 0u;
+        summary->row_id_overflow = (wide && expect_narrow) ? 1u : 0u;
+    }
 }
 
 // ---- two-pass partition in run form (radix bits 9..15) ------------------------------------------
@@ -427,6 +435,14 @@ __device__ __forceinline__ void pt_run_of(const RelArgs &r, uint32_t tile2, uint
     }
 }
 
+// where pass-2 tile `tile2` puts its first tuple of `digit` (RelArgs::cnt + RelArgs::sbase)
+constexpr uint32_t FH_SLICES = 8;
+__device__ __forceinline__ uint32_t pt_start(const RelArgs &r, uint32_t tile2, uint32_t digit, uint32_t bins)
+{
+    const uint32_t d = tile2 / r.groups, j = tile2 - d * r.groups;
+    return r.cnt[(size_t)tile2 * bins + digit] + r.sbase[((size_t)d * FH_SLICES + j / r.per) * bins + digit];
+}
+
 // cnt[tile2][digit] of pass 2 from the digit bytes pass 1 wrote.  One WAVE per pass-2 tile, no
 // workgroup barrier: the lanes hold the run table, four runs share one wave load (sixteen lanes a run, a dword of
 // four digit bytes a lane), eight such loads are in flight before their LDS atomics.  (A workgroup per tile was bound by its
@@ -503,7 +519,6 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
 // bucket histogram of the full radix = column sums of pass 2's counts per pass-1 digit
 // (grid: pass-1 digits x relations x slices of the tile groups; 1024 threads = digits x rows; full_hist zeroed by the host:
 // with few pass-1 digits — the low-radix path has 16 — one workgroup per digit summed 1600 rows alone, 0.16 ms)
-constexpr uint32_t FH_SLICES = 8;
 __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
 {
     __shared__ uint32_t part[1024];
@@ -525,37 +540,147 @@ __global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, 
     }
 }
 
-// the same when pass 1 counted (k_local_part<., true, .>): a group's strips summed give pass 2's count row of tile (d, group),
-// written here, and the rows' column sums the bucket histogram as above
-__global__ __launch_bounds__(1024) void k_cnt_from_parts(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
+// Pass 2's start offsets for the two-pass partition, in two launches (the per-tile scan kernels above took four, plus
+// k_full_from_cnt, its memset and k_full_psum).  A bucket is (pass-2 digit, pass-1 digit d) and a pass-2 tile is (d, group j),
+// so inside a bucket the tiles in front of (d, j) are just the groups j' < j: a scan along j for every (d, digit).
+// k_group_scan — grid: pass-1 digits x relations x FH_SLICES slices of the groups, 1024 threads = digits x rows — turns its
+// slice's counts into exclusive prefixes along j in place and leaves the slice's totals; FROM_PARTS: the counts are the sums
+// of a group's strips (pass 1 counted, k_local_part<., true, .>), else k_hist_runs wrote them.
+// Two phases a round of GS_ROWS groups: every thread sums up to eight digits of one group over the group's strips (16-byte
+// loads, eight in flight: with one digit a thread and 2-byte loads the kernel took 45 us on 100M + 100M tuples), the sums meet
+// in LDS, and the scan along the groups runs there.
+template <bool FROM_PARTS>
+__global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int bits, uint32_t *slice_tot)
 {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t acc[8192];                    // [rows of the round][digit]
+    __shared__ uint32_t tot[1024];                    // [row chunk][digit]
     const RelArgs &r = blockIdx.y ? r1 : r0;
     const uint32_t bins = 1u << bits, d = blockIdx.x;
-    const uint32_t b = threadIdx.x & (bins - 1u), row = threadIdx.x >> bits, rows = 1024u >> bits;
-    const uint32_t per = (r.groups + gridDim.z - 1u) / gridDim.z;
-    const uint32_t j0 = min(blockIdx.z * per, r.groups), j1 = min(j0 + per, r.groups);
-    uint32_t s = 0;
-    const uint16_t *src = r.part + (size_t)d * r.groups * r.parts * bins + b;
-    uint32_t *dst = r.cnt + (size_t)d * r.groups * bins + b;
-    for (uint32_t j = j0 + row; j < j1; j += rows) {
-        uint32_t v = 0, p = 0;
-        const uint16_t *sj = src + (size_t)j * r.parts * bins;
-        for (; p + 4 <= r.parts; p += 4) {            // (four loads in flight: one at a time this kernel took 40 us)
-            const uint32_t a0 = sj[(size_t)p * bins], a1 = sj[(size_t)(p + 1) * bins], a2 = sj[(size_t)(p + 2) * bins],
-                           a3 = sj[(size_t)(p + 3) * bins];
-            v += a0 + a1 + a2 + a3;
+    const uint32_t cpt = min(8u, bins), lanes = bins / cpt, rows = 1024u / lanes;        // digits a thread, threads a group, groups a round
+    const uint32_t row = threadIdx.x / lanes, c0 = (threadIdx.x % lanes) * cpt;
+    const uint32_t b = threadIdx.x & (bins - 1u), rr = threadIdx.x >> bits, nrr = 1024u >> bits;  // phase 2: digit, chunk of cpt rows
+    const uint32_t j0 = min(blockIdx.z * r.per, r.groups), j1 = min(j0 + r.per, r.groups);
+    uint32_t *dst = r.cnt + (size_t)d * r.groups * bins;
+    uint32_t carry = 0;
+    for (uint32_t jb = j0; jb < j1; jb += rows) {
+        const uint32_t j = jb + row;
+        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (j < j1) {
+            if (FROM_PARTS) {
+                const uint16_t *sj = r.part + ((size_t)d * r.groups + j) * r.parts * bins + c0;
+                if (cpt == 8) {
+                    for (uint32_t p = 0; p < r.parts; p += 8) {
+                        uint4 x[8];
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q)
+                            x[q] = p + q < r.parts ? *reinterpret_cast<const uint4 *>(sj + (size_t)(p + q) * bins) : uint4{0, 0, 0, 0};
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) {
+                            v[0] += x[q].x & 0xffffu; v[1] += x[q].x >> 16; v[2] += x[q].y & 0xffffu; v[3] += x[q].y >> 16;
+                            v[4] += x[q].z & 0xffffu; v[5] += x[q].z >> 16; v[6] += x[q].w & 0xffffu; v[7] += x[q].w >> 16;
+                        }
+                    }
+                } else {
+                    for (uint32_t p = 0; p < r.parts; ++p)
+                        for (uint32_t c = 0; c < cpt; ++c) v[c] += sj[(size_t)p * bins + c];
+                }
+            } else {
+                const uint32_t *sj = dst + (size_t)j * bins + c0;
+                if (cpt == 8) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(sj), y = *reinterpret_cast<const uint4 *>(sj + 4);
+                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+                } else
+                    for (uint32_t c = 0; c < cpt; ++c) v[c] = sj[c];
+            }
         }
-        for (; p < r.parts; ++p) v += sj[(size_t)p * bins];
-        dst[(size_t)j * bins] = v;
-        s += v;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c)
+            if (c < cpt) acc[row * bins + c0 + c] = v[c];
+        __syncthreads();
+        // thread (digit b, chunk rr) owns rows rr * cpt .. + cpt - 1 of the round
+        uint32_t mine = 0;
+        for (uint32_t i = 0; i < cpt; ++i) mine += acc[(rr * cpt + i) * bins + b];
+        tot[rr * bins + b] = mine;
+        __syncthreads();
+        uint32_t ex = carry, all = 0;
+        for (uint32_t q = 0; q < nrr; ++q) {
+            const uint32_t x = tot[q * bins + b];
+            ex += q < rr ? x : 0u;
+            all += x;
+        }
+        for (uint32_t i = 0; i < cpt; ++i) {
+            const uint32_t jj = jb + rr * cpt + i;
+            if (jj < j1) dst[(size_t)jj * bins + b] = ex;
+            ex += acc[(rr * cpt + i) * bins + b];
+        }
+        carry += all;
+        __syncthreads();
     }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < bins) {
-        uint32_t t = 0;
-        for (uint32_t q = 0; q < rows; ++q) t += part[q * bins + threadIdx.x];
-        if (t) atomicAdd(&full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)], t);
+    if (rr == 0)                                      // [relation][slice][bucket = digit << bits1 | d]
+        slice_tot[((size_t)blockIdx.y * FH_SLICES + blockIdx.z) * gridDim.x * bins + ((size_t)b * gridDim.x + d)] = carry;
+}
+
+// slice totals -> bucket histogram (u64) + exclusive psum of the full radix, and RelArgs::sbase: bucket start + the slices
+// in front (bucket = digit << bits1 | d).  Grid: relations x FH_SLICES — every workgroup sums and scans all buckets (32 K
+// coalesced loads at most), workgroup z writes slice z's row of sbase, workgroup 0 the histogram and the psum: sbase is read
+// by pass 2 digit-wise, so its stores are scattered, and 32 K scattered 4-byte stores from ONE compute unit took 20 us.
+// (PER > 0: buckets a thread, known at compile time — all slice totals of a thread are loaded at once and stay in registers.)
+template <int PER>
+__global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const uint32_t *slice_tot, uint32_t *sbase, uint64_t *hist,
+                                                      uint64_t *psum)
+{
+    __shared__ uint64_t sm[1024 / 64 + 1];
+    const uint32_t all_bins = 1u << (bits1 + bits), bins = 1u << bits, bins1 = 1u << bits1, zme = blockIdx.y;
+    const uint32_t *st = slice_tot + (size_t)blockIdx.x * FH_SLICES * all_bins;          // [slice][bucket]
+    uint32_t *sb = sbase + (size_t)blockIdx.x * bins1 * FH_SLICES * bins;                // [d][slice][digit]
+    uint64_t *h = hist + (size_t)blockIdx.x * all_bins, *p = psum + (size_t)blockIdx.x * all_bins;
+    const uint32_t per = PER ? (uint32_t)PER : (all_bins + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, all_bins);
+    uint64_t mine = 0;
+    if (PER) {
+        uint32_t c[PER ? PER : 1][FH_SLICES];
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+#pragma unroll
+            for (uint32_t z = 0; z < FH_SLICES; ++z) c[i][z] = b0 + i < all_bins ? st[(size_t)z * all_bins + b0 + i] : 0u;
+        uint32_t t[PER ? PER : 1], front[PER ? PER : 1];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            t[i] = 0; front[i] = 0;
+#pragma unroll
+            for (uint32_t z = 0; z < FH_SLICES; ++z) { front[i] += z < zme ? c[i][z] : 0u; t[i] += c[i][z]; }
+            mine += t[i];
+        }
+        uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t bk = b0 + i;
+            if (bk < all_bins) {
+                if (zme == 0) { h[bk] = t[i]; p[bk] = base; }
+                sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + front[i];   // (mod 2^32,
+                base += t[i];                                                                                            //  like the tile counts)
+            }
+        }
+        return;
+    }
+    for (uint32_t bk = b0; bk < b1; ++bk) {
+        uint32_t c[FH_SLICES], t = 0;
+#pragma unroll
+        for (uint32_t z = 0; z < FH_SLICES; ++z) c[z] = st[(size_t)z * all_bins + bk];
+#pragma unroll
+        for (uint32_t z = 0; z < FH_SLICES; ++z) t += c[z];
+        mine += t;
+    }
+    uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
+    for (uint32_t bk = b0; bk < b1; ++bk) {
+        uint32_t c[FH_SLICES], t = 0, front = 0;
+#pragma unroll
+        for (uint32_t z = 0; z < FH_SLICES; ++z) c[z] = st[(size_t)z * all_bins + bk];
+#pragma unroll
+        for (uint32_t z = 0; z < FH_SLICES; ++z) { front += z < zme ? c[z] : 0u; t += c[z]; }
+        if (zme == 0) { h[bk] = t; p[bk] = base; }
+        sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + front;
+        base += t;
     }
 }
 
@@ -681,7 +806,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
 
     uint32_t nphys = 0, nlen = 0, ngb = 0;            // the NEXT tile's run (thread i: run i) and output positions, prefetched
     pt_run_of(r, tile2, threadIdx.x, nphys, nlen);
-    if (threadIdx.x < bins) ngb = r.cnt[(size_t)tile2 * bins + threadIdx.x];
+    if (threadIdx.x < bins) ngb = pt_start(r, tile2, threadIdx.x, bins);
     uint32_t buf = 0;
     uint32_t total = build_runs(buf, nphys, nlen, ngb);
     {
@@ -689,7 +814,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
         nphys = 0; nlen = 0;
         if (nt < t_end) {
             pt_run_of(r, nt, threadIdx.x, nphys, nlen);
-            if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+            if (threadIdx.x < bins) ngb = pt_start(r, nt, threadIdx.x, bins);
         }
     }
     for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
@@ -781,7 +906,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             nphys = 0; nlen = 0;
             if (nt < t_end) {
                 pt_run_of(r, nt, threadIdx.x, nphys, nlen);
-                if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+                if (threadIdx.x < bins) ngb = pt_start(r, nt, threadIdx.x, bins);
             }
         }
         SR_STAMP(6);
@@ -849,7 +974,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
     uint32_t nphys = 0, nlen = 0, ngb = 0;
     if (t_first < t_end) {
         pt_run_of(r, t_first, threadIdx.x, nphys, nlen);
-        if (threadIdx.x < bins) ngb = r.cnt[(size_t)t_first * bins + threadIdx.x];
+        if (threadIdx.x < bins) ngb = pt_start(r, t_first, threadIdx.x, bins);
     }
     for (uint32_t tile2 = t_first; tile2 < t_end; tile2 += tstep) {
     uint32_t total;
@@ -865,7 +990,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
         nphys = 0; nlen = 0;
         if (nt < t_end) {
             pt_run_of(r, nt, threadIdx.x, nphys, nlen);
-            if (threadIdx.x < bins) ngb = r.cnt[(size_t)nt * bins + threadIdx.x];
+            if (threadIdx.x < bins) ngb = pt_start(r, nt, threadIdx.x, bins);
         }
     }
     __syncthreads();
