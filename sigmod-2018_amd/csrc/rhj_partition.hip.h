@@ -327,11 +327,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     const uint64_t lt = lanemask_lt();
     bool wide = false;
 
-    for (; tile < tile_end; ++tile) {                 // (one tile unless H2; the barriers of a round keep the rounds apart.
-    const uint64_t beg = (uint64_t)tile * PT_TILE;    //  The strip costs this kernel 5 %: a tile's stores now drain in front of
-    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);   // the next tile's barrier instead of behind the
-    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;        // workgroup's end; reading the next tile before
-                                                                          // the write-out made it 10 %.)
+    // (one tile unless H2; the barriers of a round keep the rounds apart.  Counting costs this kernel 5 %: 4096 LDS atomics a
+    // tile at about two lanes a clock, wherever they are issued — rank loop or write-out; neither reading the next tile before
+    // this tile's write-out nor barriers that wait for LDS traffic only, s_waitcnt lgkmcnt(0) + s_barrier, changed anything.)
+    for (; tile < tile_end; ++tile) {
+    const uint64_t beg = (uint64_t)tile * PT_TILE;
+    const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
+    const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+
     for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
 
     uint4 t[PT_V];
@@ -352,10 +355,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
         if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << (shift + bits + next_bits)) - 1u)) - r.range_lo) < r.range_span;
         dig[k] = d;
-        if (H2 && ok[k]) {
-            const uint32_t cell = (d << next_bits) | ((uint32_t)(key >> next_shift) & ((1u << next_bits) - 1u));
-            atomicAdd(&h2[cell >> 1], 1u << ((cell & 1u) * 16u));
-        }
         uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
         for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
             const uint64_t m = __ballot(ok[k] && ((d >> b) & 1u));
@@ -408,6 +407,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
             if (T12) { out12[p] = Tuple12{v.x, v.y, v.z}; wide = wide || v.w != 0; }
             else out[p] = v;
             if (DIG) dg[p] = (uint8_t)((v.x >> next_shift) & ((1u << next_bits) - 1u));
+            if (H2) {
+                const uint32_t cell = (((v.x >> shift) & mask) << next_bits) | ((v.x >> next_shift) & ((1u << next_bits) - 1u));
+                atomicAdd(&h2[cell >> 1], 1u << ((cell & 1u) * 16u));
+            }
         }
     }
     }

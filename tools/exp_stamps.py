@@ -40,7 +40,7 @@ for name, a, b in (("build", 0, 1), ("phase1(w0)", 1, 2), ("chain+barrier", 2, 3
 ok = t[:, 5] > 0
 d = us(t[ok, 6] - t[ok, 5]) if ok.any() else np.zeros(1); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (thread 0's own emit span)" % ("deferred emit (w0)", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 ok7 = t[:, 7] > 0
-d = us(t[ok7, 7] - t[ok7, 2]); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (w0 after phase 1 -> all waves through the previous unit's emit)" % ("ph1 skew + prev emit", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+d = us(t[ok7, 7] - t[ok7, 2]) if ok7.any() else np.zeros(1); print("%-28s mean %.1f  p50 %.1f  p90 %.1f  max %.1f us   (w0 after phase 1 -> all waves through the previous unit's emit)" % ("ph1 skew + prev emit", d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 starts = np.sort(us(t[:, 0] - t0))
 print("start times of units 0,255,256,511,1024,last: ", [round(float(starts[min(i, units - 1)]), 1) for i in (0, 255, 256, 511, 1024, units - 1)])
 if units <= 256:
