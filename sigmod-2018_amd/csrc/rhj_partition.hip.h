@@ -382,12 +382,27 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
         }
         mytotal = run;
     }
-    uint64_t kept64;                                      // the tile's tuples that stay (all of them unless the join is sharded)
-    const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, &kept64, sm);
-    const uint32_t kept = RANGED ? (uint32_t)kept64 : count;
-    if (threadIdx.x < bins) dstart[threadIdx.x] = (uint32_t)ds;
-    if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : kept);
-    __syncthreads();
+    uint32_t kept = count;                                // the tile's tuples that stay (all of them unless the join is sharded)
+    if (bins <= (uint32_t)WAVE) {                         // the digits are wave 0's lanes: a wave scan, not a workgroup scan (three barriers)
+        if (w == 0) {
+            uint32_t tot;
+            const uint32_t ds = wave_excl_scan_u32((uint32_t)mytotal, &tot);
+            if (lane < bins) { dstart[lane] = ds; r.runs[(size_t)lane * r.tiles + tile] = (uint16_t)ds; }
+            if (lane == 0) {
+                r.runs[(size_t)bins * r.tiles + tile] = (uint16_t)(RANGED ? tot : count);
+                if (RANGED) dstart[bins] = tot;
+            }
+        }
+        __syncthreads();
+        if (RANGED) kept = dstart[bins];
+    } else {
+        uint64_t kept64;
+        const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, &kept64, sm);
+        if (RANGED) kept = (uint32_t)kept64;
+        if (threadIdx.x < bins) dstart[threadIdx.x] = (uint32_t)ds;
+        if (threadIdx.x <= bins) r.runs[(size_t)threadIdx.x * r.tiles + tile] = (uint16_t)(threadIdx.x < bins ? (uint32_t)ds : kept);
+        __syncthreads();
+    }
 
     // (staging 12-byte tuples as three word arrays, the big win of pass 2, measured +-0 here; the digit bytes as one 8-byte
     // store per thread +15 %: this kernel sits on the HBM limit)
@@ -768,8 +783,23 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
     // run table of a tile: scan of the run lengths the threads hold -> runoff / rbase of buffer `buf` (entries from `group` on
     // hold the tile's total, also in runoff[PT_MAX_GROUP]); the tile's output positions per digit -> gbase (the previous
     // tile's last batch has consumed gbase)
+    // (At most 64 runs — 64 pass-1 digits or fewer — are wave 0's alone: one wave scan instead of a workgroup scan and its three
+    // barriers, which cost every batch 1.5 of its 10 us; the caller reads the tile's total from the table behind its next barrier.
+    // With more runs, up to four a lane of wave 0, that wave became the straggler: 100M x 1B at 14 bits +12 %.)
+    const bool wave_runs = r.group <= (uint32_t)WAVE;  // (workgroup-uniform)
     auto build_runs = [&](uint32_t buf, uint32_t phys, uint32_t len, uint32_t gb) {
         uint32_t *runoff = runoff0 + buf * SR_RUNOFF, *rbase = rbase0 + buf * PT_MAX_GROUP;
+        if (wave_runs) {
+            if (w == 0) {
+                uint32_t tot;
+                const uint32_t off = wave_excl_scan_u32(len, &tot);
+                runoff[lane] = lane < r.group ? off : tot;
+                for (uint32_t i = WAVE + lane; i < SR_RUNOFF; i += WAVE) runoff[i] = tot;
+                rbase[lane] = phys - off;
+            }
+            if (threadIdx.x < bins) gbase[threadIdx.x] = gb;
+            return 0u;
+        }
         uint64_t tot64;
         const uint32_t off = (uint32_t)block_excl_scan<PT_BLOCK>(len, &tot64, sm);
         if (threadIdx.x < SR_RUNOFF) runoff[threadIdx.x] = threadIdx.x < r.group ? off : (uint32_t)tot64;
@@ -822,6 +852,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
     }
     for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
     __syncthreads();
+    if (wave_runs) total = runoff0[buf * SR_RUNOFF + SR_RUNOFF - 1];
     uint32_t sb = 0;
     uint32_t count = min((uint32_t)SR_TILE, total);
     issue_loads(buf, sb, count);
@@ -871,7 +902,12 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             }
             mytotal = run;
         }
-        const uint64_t ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+        uint64_t ds;
+        if (bins <= (uint32_t)WAVE) {                 // the digits are wave 0's lanes: a wave scan, no workgroup scan (workgroup-uniform)
+            uint32_t unused;
+            ds = w == 0 ? wave_excl_scan_u32((uint32_t)mytotal, &unused) : 0u;
+        } else
+            ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
         if (threadIdx.x < bins) {
             dstart[threadIdx.x] = (uint32_t)ds;
             const uint32_t gb = gbase[threadIdx.x];
@@ -915,6 +951,7 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
         SR_STAMP(6);
         __syncthreads();                              // staged tile, run table and gbase are visible
         SR_STAMP(7);
+        if (next_tile && wave_runs) total = runoff0[buf * SR_RUNOFF + SR_RUNOFF - 1];
         sb = nsb;
         if (more) {
             count = min((uint32_t)SR_TILE, total - sb);
