@@ -94,7 +94,7 @@ struct Ctx {
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
-    Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, fullhist, units, bunits, ldsb, meta, summary,
+    Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, units, bunits, ldsb, meta, summary,
         ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status, stripR, stripS, slice_tot, sbase;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
@@ -1321,7 +1321,7 @@ void rhj_release(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.fullhist, &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.slice_tot, &g.sbase, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.slice_tot, &g.sbase, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);

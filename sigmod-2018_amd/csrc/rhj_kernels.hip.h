@@ -7,6 +7,7 @@
 //   k_scatter_lds    SerialReorderArray scatter   preprocess.c:349-359 (stable)
 //   k_plan           bucket loop / side choice    rhjoin.c:79-102 (>= picks the probe side)
 //   k_local_part / k_scatter_runs   the same stable scatter in two LSD passes (radix bits 9..15)
+//   k_group_scan / k_bucket_psum    hist merge + psum for the two passes   preprocess.c:83-102 / :328-340
 //   fj_build / k_build_lds / k_build_hbm   InitIndex + CreateIndex   rhjoin.c:253-273, :219-250
 //   k_join_fused / k_join_walk / k_probe   GetResults + MergeResults   rhjoin.c:141-217, :354-392
 //   k_filter_*       Filter                       filter.c:110-183
@@ -16,8 +17,10 @@
 //                          4096-tuple tile ranked by wave match-any ballots + per-wave LDS counters, staged in LDS in digit
 //                          order, written run by run).  Bits 9..15: two LSD passes in RUN FORM — k_local_part partitions every
 //                          tile in place on the low half of the bits (no histogram, no offsets; 12-byte tuples when the row ids
-//                          fit 32 bits), k_hist_runs / k_scan_* give pass 2 its offsets from one byte per tuple, k_scatter_runs
-//                          moves the runs to their final places (software-pipelined, persistent, XCD-aware tile order).
+//                          fit 32 bits) and, up to 12 bits, counts pass 2's digits on the way (strips of 4 tiles, cells in LDS;
+//                          13..15 bits: k_hist_runs from one byte per tuple); k_group_scan / k_bucket_psum turn the counts into
+//                          pass 2's offsets and the bucket histogram; k_scatter_runs moves the runs to their final places
+//                          (software-pipelined, persistent, XCD-aware tile order).  Five launches, no memset.
 //   rhj_small.hip.h        joins of up to 4 M tuples per side on <= 8 bits: the partition in two launches, the plan riding along.
 //   rhj_join_fused.hip.h   the default join: one persistent workgroup per CU takes (bucket, <= 65536 probe tuples) units by
 //                          ticket; per unit a CSR slot index of the build side in LDS ((tag16, position) entries sorted

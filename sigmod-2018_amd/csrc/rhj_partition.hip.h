@@ -134,25 +134,6 @@ __global__ __launch_bounds__(256) void k_scan_apply(RelArgs r0, RelArgs r1, int 
     }
 }
 
-// Bucket histogram (u32, from k_hist_tiles' atomics) -> u64 hist + exclusive psum.
-__global__ __launch_bounds__(1024) void k_full_psum(int bits, const uint32_t *full_hist, uint64_t *hist, uint64_t *psum)
-{
-    __shared__ uint64_t sm[1024 / 64 + 1];
-    const uint32_t bins = 1u << bits;
-    const uint32_t *f = full_hist + (size_t)blockIdx.x * bins;
-    uint64_t *h = hist + (size_t)blockIdx.x * bins, *p = psum + (size_t)blockIdx.x * bins;
-    const uint32_t per = (bins + 1023) / 1024;
-    const uint32_t b0 = threadIdx.x * per;
-    uint64_t mine = 0;
-    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) mine += f[b];
-    uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
-    for (uint32_t b = b0; b < min(b0 + per, bins); ++b) {
-        h[b] = f[b];
-        p[b] = base;
-        base += f[b];
-    }
-}
-
 // One stable partition pass on digit = (key >> shift) & ((1 << bits) - 1), bits <= 8.
 // Tile order in memory is (wave, round, lane); a tuple's stable rank inside its digit is
 //   digit_start + (same digit in earlier waves) + (same digit in earlier rounds of this
@@ -534,32 +515,8 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
     }
 }
 
-// bucket histogram of the full radix = column sums of pass 2's counts per pass-1 digit
-// (grid: pass-1 digits x relations x slices of the tile groups; 1024 threads = digits x rows; full_hist zeroed by the host:
-// with few pass-1 digits — the low-radix path has 16 — one workgroup per digit summed 1600 rows alone, 0.16 ms)
-__global__ __launch_bounds__(1024) void k_full_from_cnt(RelArgs r0, RelArgs r1, int bits1, int bits, uint32_t *full_hist)
-{
-    __shared__ uint32_t part[1024];
-    const RelArgs &r = blockIdx.y ? r1 : r0;
-    const uint32_t bins = 1u << bits, d = blockIdx.x;
-    const uint32_t b = threadIdx.x & (bins - 1u), row = threadIdx.x >> bits, rows = 1024u >> bits;
-    const uint32_t per = (r.groups + gridDim.z - 1u) / gridDim.z;
-    const uint32_t j0 = min(blockIdx.z * per, r.groups), j1 = min(j0 + per, r.groups);
-    uint32_t s = 0;
-    const uint32_t *base = r.cnt + (size_t)d * r.groups * bins + b;
-#pragma unroll 4
-    for (uint32_t j = j0 + row; j < j1; j += rows) s += base[(size_t)j * bins];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < bins) {
-        uint32_t t = 0;
-        for (uint32_t q = 0; q < rows; ++q) t += part[q * bins + threadIdx.x];
-        if (t) atomicAdd(&full_hist[((size_t)blockIdx.y << (bits1 + bits)) + ((threadIdx.x << bits1) | d)], t);
-    }
-}
-
-// Pass 2's start offsets for the two-pass partition, in two launches (the per-tile scan kernels above took four, plus
-// k_full_from_cnt, its memset and k_full_psum).  A bucket is (pass-2 digit, pass-1 digit d) and a pass-2 tile is (d, group j),
+// Pass 2's start offsets for the two-pass partition, in two launches (the per-tile scan kernels above took four, plus a
+// bucket-histogram kernel, its memset and a psum kernel behind the scatter).  A bucket is (pass-2 digit, pass-1 digit d) and a pass-2 tile is (d, group j),
 // so inside a bucket the tiles in front of (d, j) are just the groups j' < j: a scan along j for every (d, digit).
 // k_group_scan — grid: pass-1 digits x relations x FH_SLICES slices of the groups, 1024 threads = digits x rows — turns its
 // slice's counts into exclusive prefixes along j in place and leaves the slice's totals; FROM_PARTS: the counts are the sums
