@@ -45,6 +45,7 @@ WORKLOADS = {
     "c3b14": dict(nR=100_000_000, nS=100_000_000, bits=14, dist="uniform", name="100Mx100M uniform u64 FK, 14 radix bits (not a BASELINE config: shows the LDS-resident path)"),
     "c3b13": dict(nR=100_000_000, nS=100_000_000, bits=13, dist="uniform", name="100Mx100M uniform u64 FK, 13 radix bits (experiment)"),
     "c3b15": dict(nR=100_000_000, nS=100_000_000, bits=15, dist="uniform", name="100Mx100M uniform u64 FK, 15 radix bits (experiment)"),
+    "m16b8": dict(nR=16_000_000, nS=16_000_000, bits=8, dist="uniform", name="16Mx16M uniform u64 FK, 8 radix bits (experiment: mid-size join on the low-radix path)"),
     "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
     # BASELINE configs[4]: the SIGMOD'18 `small` workload through the reference's own driver and query executor
     # linked against librhj.so (device-resident configuration); the 50 queries are dealt round-robin to the ranks

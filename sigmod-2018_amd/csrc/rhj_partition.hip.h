@@ -538,28 +538,54 @@ __global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int
     uint32_t *dst = r.cnt + (size_t)d * r.groups * bins;
     uint32_t carry = 0;
     for (uint32_t jb = j0; jb < j1; jb += rows) {
-        const uint32_t j = jb + row;
         uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (j < j1) {
-            if (FROM_PARTS) {
-                const uint16_t *sj = r.part + ((size_t)d * r.groups + j) * r.parts * bins + c0;
-                if (cpt == 8) {
-                    for (uint32_t p = 0; p < r.parts; p += 8) {
-                        uint4 x[8];
+        if (FROM_PARTS) {
+            // The round's R groups times S = rows / R shares of a group's strips keep all threads busy: with 256 pass-1 digits
+            // (the low-radix path on 8 bits) a slice has 3 groups of 56 strips, and three threads loading 56 strips each in
+            // 4096 such workgroups took 0.11 ms.  The shares meet in LDS by atomic adds.
+            const uint32_t R = min(rows, j1 - jb);
+            uint32_t S = max(1u, min(rows / R, r.parts));
+            if (S < 4u) S = 1;                        // (no shares: plain stores, no clearing — 100M + 100M at 12 bits has S = 2: 35 vs 40 us)
+            if (S > 1u) {
+                for (uint32_t i = threadIdx.x; i < rows * bins; i += 1024u) acc[i] = 0;
+                __syncthreads();
+            }
+            const uint32_t jr = row / S, sp = row - jr * S;
+            if (jr < R) {
+                const uint16_t *sj = r.part + ((size_t)d * r.groups + jb + jr) * r.parts * bins + c0;
+                // a thread's digits of one strip in ONE load (16, 8 or 4 bytes), eight strips in flight
+                for (uint32_t p = sp; p < r.parts; p += 8 * S) {
+                    uint4 x[8];
 #pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q)
-                            x[q] = p + q < r.parts ? *reinterpret_cast<const uint4 *>(sj + (size_t)(p + q) * bins) : uint4{0, 0, 0, 0};
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q) {
-                            v[0] += x[q].x & 0xffffu; v[1] += x[q].x >> 16; v[2] += x[q].y & 0xffffu; v[3] += x[q].y >> 16;
-                            v[4] += x[q].z & 0xffffu; v[5] += x[q].z >> 16; v[6] += x[q].w & 0xffffu; v[7] += x[q].w >> 16;
+                    for (uint32_t q = 0; q < 8; ++q) {
+                        x[q] = uint4{0, 0, 0, 0};
+                        if (p + q * S < r.parts) {
+                            const uint16_t *at = sj + (size_t)(p + q * S) * bins;
+                            if (cpt == 8) x[q] = *reinterpret_cast<const uint4 *>(at);
+                            else if (cpt == 4) { const uint2 y = *reinterpret_cast<const uint2 *>(at); x[q].x = y.x; x[q].y = y.y; }
+                            else x[q].x = *reinterpret_cast<const uint32_t *>(at);
                         }
                     }
-                } else {
-                    for (uint32_t p = 0; p < r.parts; ++p)
-                        for (uint32_t c = 0; c < cpt; ++c) v[c] += sj[(size_t)p * bins + c];
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q) {
+                        v[0] += x[q].x & 0xffffu; v[1] += x[q].x >> 16; v[2] += x[q].y & 0xffffu; v[3] += x[q].y >> 16;
+                        v[4] += x[q].z & 0xffffu; v[5] += x[q].z >> 16; v[6] += x[q].w & 0xffffu; v[7] += x[q].w >> 16;
+                    }
                 }
-            } else {
+                if (S > 1u) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 8; ++c)
+                        if (c < cpt && v[c]) atomicAdd(&acc[jr * bins + c0 + c], v[c]);
+                }
+            }
+            if (S == 1u) {                            // (jr == row; rows behind the slice's end store zeros)
+#pragma unroll
+                for (uint32_t c = 0; c < 8; ++c)
+                    if (c < cpt) acc[row * bins + c0 + c] = v[c];
+            }
+        } else {
+            const uint32_t j = jb + row;
+            if (j < j1) {
                 const uint32_t *sj = dst + (size_t)j * bins + c0;
                 if (cpt == 8) {
                     const uint4 x = *reinterpret_cast<const uint4 *>(sj), y = *reinterpret_cast<const uint4 *>(sj + 4);
@@ -567,10 +593,10 @@ __global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int
                 } else
                     for (uint32_t c = 0; c < cpt; ++c) v[c] = sj[c];
             }
-        }
 #pragma unroll
-        for (uint32_t c = 0; c < 8; ++c)
-            if (c < cpt) acc[row * bins + c0 + c] = v[c];
+            for (uint32_t c = 0; c < 8; ++c)
+                if (c < cpt) acc[row * bins + c0 + c] = v[c];
+        }
         __syncthreads();
         // thread (digit b, chunk rr) owns rows rr * cpt .. + cpt - 1 of the round
         uint32_t mine = 0;
@@ -578,7 +604,8 @@ __global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int
         tot[rr * bins + b] = mine;
         __syncthreads();
         uint32_t ex = carry, all = 0;
-        for (uint32_t q = 0; q < nrr; ++q) {
+        const uint32_t live = min(nrr, (min(rows, j1 - jb) + cpt - 1u) / cpt);        // chunks with groups in them (the others hold zeros)
+        for (uint32_t q = 0; q < live; ++q) {
             const uint32_t x = tot[q * bins + b];
             ex += q < rr ? x : 0u;
             all += x;
