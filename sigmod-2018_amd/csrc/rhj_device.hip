@@ -394,7 +394,7 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     }
 #define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), 0, g.stream, lo, hi, (const uint32_t *)g.slice_tot.p, \
                             (uint32_t *)g.sbase.p, ps.hist, ps.psum)
-    if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else RHJ_BP(0);
+    if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else if (bits == 13) RHJ_BP(8); else RHJ_BP(0);
 #undef RHJ_BP
     RHJ_STAGE(ST_SCATTER);
     uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search

@@ -665,24 +665,38 @@ __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const
         }
         return;
     }
-    for (uint32_t bk = b0; bk < b1; ++bk) {
-        uint32_t c[FH_SLICES], t = 0;
+    // any count: four buckets at a time, their 32 slice totals in flight together (one bucket after the other: 67 us for 8192)
+    constexpr uint32_t CH = 4;
+    for (uint32_t c0 = b0; c0 < b1; c0 += CH) {
+        uint32_t c[CH][FH_SLICES];
 #pragma unroll
-        for (uint32_t z = 0; z < FH_SLICES; ++z) c[z] = st[(size_t)z * all_bins + bk];
+        for (uint32_t i = 0; i < CH; ++i)
 #pragma unroll
-        for (uint32_t z = 0; z < FH_SLICES; ++z) t += c[z];
-        mine += t;
+            for (uint32_t z = 0; z < FH_SLICES; ++z) c[i][z] = c0 + i < b1 ? st[(size_t)z * all_bins + c0 + i] : 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < CH; ++i)
+#pragma unroll
+            for (uint32_t z = 0; z < FH_SLICES; ++z) mine += c[i][z];
     }
     uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
-    for (uint32_t bk = b0; bk < b1; ++bk) {
-        uint32_t c[FH_SLICES], t = 0, front = 0;
+    for (uint32_t c0 = b0; c0 < b1; c0 += CH) {
+        uint32_t c[CH][FH_SLICES];
 #pragma unroll
-        for (uint32_t z = 0; z < FH_SLICES; ++z) c[z] = st[(size_t)z * all_bins + bk];
+        for (uint32_t i = 0; i < CH; ++i)
 #pragma unroll
-        for (uint32_t z = 0; z < FH_SLICES; ++z) { front += z < zme ? c[z] : 0u; t += c[z]; }
-        if (zme == 0) { h[bk] = t; p[bk] = base; }
-        sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + front;
-        base += t;
+            for (uint32_t z = 0; z < FH_SLICES; ++z) c[i][z] = c0 + i < b1 ? st[(size_t)z * all_bins + c0 + i] : 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < CH; ++i) {
+            const uint32_t bk = c0 + i;
+            if (bk < b1) {
+                uint32_t t = 0, front = 0;
+#pragma unroll
+                for (uint32_t z = 0; z < FH_SLICES; ++z) { front += z < zme ? c[i][z] : 0u; t += c[i][z]; }
+                if (zme == 0) { h[bk] = t; p[bk] = base; }
+                sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + front;
+                base += t;
+            }
+        }
     }
 }
 
