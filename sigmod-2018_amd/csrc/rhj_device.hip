@@ -194,6 +194,7 @@ int ctx_init()
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_small_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(PT_MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_psum<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8u << 14)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     {
@@ -392,9 +393,10 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
                    b0, b1, hi);
         RHJ_LAUNCH((k_group_scan<false>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p);
     }
-#define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), 0, g.stream, lo, hi, (const uint32_t *)g.slice_tot.p, \
-                            (uint32_t *)g.sbase.p, ps.hist, ps.psum)
-    if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else if (bits == 13) RHJ_BP(8); else RHJ_BP(0);
+    const int staged = bits >= 13 && bits <= 14;      // (15 bits: 256 KiB of totals do not fit LDS)
+#define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), staged ? (size_t)bins * 8 : 0, g.stream, lo, hi, \
+                            (const uint32_t *)g.slice_tot.p, (uint32_t *)g.sbase.p, ps.hist, ps.psum, staged)
+    if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else RHJ_BP(0);
 #undef RHJ_BP
     RHJ_STAGE(ST_SCATTER);
     uint32_t search0 = 1;                             // largest power of two <= group: first step of the run search
@@ -634,7 +636,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             if (ensure(g.status, (unit_bound + 1) * 8 + 64)) return -1;
             pa.zero = (uint32_t *)g.status.p; pa.zero_words = (uint32_t)(((unit_bound + 1) * 8 + 64) / 4);
         }
-        if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, bits);
+        if (!ps.plan_done) RHJ_LAUNCH(k_plan, dim3(bits >= 11 ? 8 : 1), dim3(1024), 0, g.stream, pa, bits);
         else if (want_fused) HIP_TRY(hipMemsetAsync(g.status.p, 0, (unit_bound + 1) * 8 + 64, g.stream));
         pa.zero = nullptr; pa.zero_words = 0;
     } else {
@@ -865,7 +867,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = LDS_BUDGET / 4 / 4 * 4; pa.build_chunk = build_chunk; pa.span_lds = FJ_SPAN;
     pa.parent_mask = (1u << r) - 1u; pa.parent_flip = parent_flip; pa.zero = nullptr; pa.zero_words = 0;
-    RHJ_LAUNCH(k_plan, dim3(1), dim3(1024), 0, g.stream, pa, T);
+    RHJ_LAUNCH(k_plan, dim3(T >= 11 ? 8 : 1), dim3(1024), 0, g.stream, pa, T);
 
     JoinArgs ja;
     ja.partR = (const rhj_tuple *)g.partR.p; ja.partS = (const rhj_tuple *)g.partS.p;
