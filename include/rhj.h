@@ -163,6 +163,10 @@ void rhj_set_small(int on);
  * force (csrc/rhj_lowradix.hip.h); 0: such joins take the tiled path with hash tables in HBM.  Results are identical
  * either way (env RHJ_NO_LOWRADIX=1). */
 void rhj_set_lowradix(int on);
+/* 1 (default): the two-pass partition's first pass counts the second pass' digits itself at radix widths up to 12 bits
+ * (csrc/rhj_partition.hip.h, k_local_part); 0: a kernel of its own counts them from one byte per tuple at every width, as
+ * it does at 13..15 bits.  Results are identical either way (env RHJ_NO_COUNT_IN_PASS1=1; for A/B and tests). */
+void rhj_set_count_in_pass1(int on);
 /* Pair order (env RHJ_ORDER=canonical|any).  0 = canonical (default): the reference's order for the
  * radix width in force — bucket ascending, probe side = R iff cR >= cS, probe tuples in input order, build matches
  * in descending position (rhjoin.c:42-57,86,141-250).  1 = any: the same pairs in the canonical order of a radix

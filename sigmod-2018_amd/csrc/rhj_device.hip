@@ -1123,6 +1123,7 @@ void rhj_set_fused(int on) { g.no_fused = !on; g.force_fused = on >= 2; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
 void rhj_set_lowradix(int on) { g.no_lowradix = !on; }
+void rhj_set_count_in_pass1(int on) { g.no_count_in_pass1 = !on; }
 void rhj_set_order(int any) { g.order_any = any != 0; }
 int rhj_auto_radix_bits(uint64_t nR, uint64_t nS) { return auto_radix_bits(nR, nS); }
 int rhj_get_order(void) { return g.order_any; }

@@ -154,6 +154,55 @@ def test_partition_matches_oracle(rhj, oracle, bits):
         assert (got == want).all(), "partition differs (n=%d bits=%d)" % (n, bits)
 
 
+@pytest.mark.parametrize("bits", [9, 10, 12])
+def test_partition_counts_from_digit_bytes_match_the_counts_of_pass_1(rhj, oracle, bits):
+    """Up to 12 radix bits pass 1 counts pass 2's digits itself (strips of tiles, cells in LDS); the digit-byte kernel that
+    serves 13..15 bits can be forced at any width: both must give the oracle's partition, also on skewed keys and on a
+    relation that ends inside a strip."""
+    try:
+        for n, kind, dom in ((4096 * 5 + 17, 4, 1 << 30), (700001, 1, 100000), (1200000, 2, 2000), (300000, 4, 1)):
+            rel = oracle.generate(n, kind, dom, 0.9, 300 + bits)
+            want, hist, psum = oracle.partition(rel, bits)
+            for on in (1, 0):
+                rhj.lib.rhj_set_count_in_pass1(on)
+                out, h, p = rhj.partition_device(rhj.to_device(rel), bits)
+                got = out.cpu().numpy().view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
+                assert (h == hist).all() and (p == psum).all() and (got == want).all(), (n, bits, on)
+    finally:
+        rhj.lib.rhj_set_count_in_pass1(1)
+
+
+def test_row_id_width_is_speculated_and_a_wrong_guess_runs_again():
+    """The 16-byte kernels of the two-pass partition are not launched until a join of the process has needed them: the first
+    join with wide row ids is reported as an overflow by the sample and run again wide; later joins launch both widths."""
+    import subprocess, sys, os
+    code = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+from pyoracle import Oracle
+o = Oracle()
+mod = importlib.import_module("sigmod-2018_amd"); rhj = mod.RHJ(device=0)
+rhj.set_bits(12)
+R = o.generate(150000, 0, 0, 0.0, 5); S = o.generate(210000, 1, 150000, 0.0, 6)
+wide = np.uint64(1) << np.uint64(45)
+def run(R, S):
+    t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), capacity=len(S))
+    got = rhj.pairs_to_numpy(t); want = o.join(R, S, 12)
+    assert m == len(want) and (got == want).all()
+run(R, S)                                    # narrow: the 12-byte kernels alone
+Rw = R.copy(); Rw["row_id"][:7] += wide
+run(Rw, S)                                   # wide at the ends: the sample sees it, nothing was launched for it -> again, wide
+run(R, S)                                    # narrow again, both widths launched from now on
+Sm = S.copy(); Sm["row_id"][len(S) // 2] += wide
+run(R, Sm)                                   # wide in the middle: pass 1 catches it
+run(Rw, Sm)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0 and b"ok" in res.stdout, res.stderr.decode()[-1500:]
+
+
 @pytest.mark.parametrize("bits,nR,nS,kind,dom", [
     (3, 1000, 1, 4, 10), (7, 77777, 99999, 1, 50000), (9, 200000, 1000, 4, 1 << 20),
     (12, 2000000, 3000000, 1, 2000000), (12, 100000, 3000000, 2, 100000), (4, 50000, 60000, 4, 11),
