@@ -46,6 +46,7 @@ WORKLOADS = {
     "c3b13": dict(nR=100_000_000, nS=100_000_000, bits=13, dist="uniform", name="100Mx100M uniform u64 FK, 13 radix bits (experiment)"),
     "c3b15": dict(nR=100_000_000, nS=100_000_000, bits=15, dist="uniform", name="100Mx100M uniform u64 FK, 15 radix bits (experiment)"),
     "m16b8": dict(nR=16_000_000, nS=16_000_000, bits=8, dist="uniform", name="16Mx16M uniform u64 FK, 8 radix bits (experiment: mid-size join on the low-radix path)"),
+    "c3half": dict(nR=100_000_000, nS=100_000_000, bits=12, dist="half", name="100Mx100M uniform u64, half of S without a partner, 12 radix bits (experiment: the foreign-key speculation fails)"),
     "dense": dict(nR=1_000_000, nS=1_000_000, bits=8, dist="dense", name="1Mx1M dense keys j+1, 8 radix bits"),
     # BASELINE configs[4]: the SIGMOD'18 `small` workload through the reference's own driver and query executor
     # linked against librhj.so (device-resident configuration); the 50 queries are dealt round-robin to the ranks
@@ -109,6 +110,8 @@ def make_relations(w, device, seed):
         R[:, 0] = mix64(torch.randperm(nR, generator=gen, device=device))
         if w["dist"] == "zipf":
             S[:, 0] = mix64(zipf_ranks(nS, nR, 0.9, gen, device))
+        elif w["dist"] == "half":
+            S[:, 0] = mix64(torch.randint(0, 2 * nR, (nS,), generator=gen, device=device))
         else:
             for a in range(0, nS, 1 << 27):
                 b = min(nS, a + (1 << 27))
@@ -597,7 +600,11 @@ def main():
         fused = st["path"] in ("fused", "small")
         lowradix = st["path"] == "lowradix"
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
-        probe_kernel = ("k_join_fused (LDS index build + probe + emit, one kernel; k_join_walk behind it returns at once on foreign-key joins)" if fused
+        spec = int(rhj.lib.rhj_last_spec()) if fused and not small else 0      # 0 not tried, 1 the foreign-key speculation held, 2 failed
+        probe_kernel = ("k_join_spec (the fused join kernel on the foreign-key speculation, which held: LDS index build + probe, pairs of the "
+                        "foreign-key side's units written from the probe loop, no stash, no chained offsets; k_join_fused and k_join_walk "
+                        "behind it return at once)" if fused and spec == 1
+                        else "k_join_fused (LDS index build + probe + emit, one kernel; k_join_walk behind it returns at once on foreign-key joins)" if fused
                         else "k_join_fused on the finer buckets + k_lr_totals + k_lr_emit (internal join, then the pairs in the canonical order "
                              "of the caller's radix: the whole probe phase of the low-radix path)" if lowradix
                         else "k_probe<WRITE> (emit pass of the tiled path)")
@@ -609,7 +616,7 @@ def main():
             cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.workload)) if "subsplit" not in f)
             if cands and fused:
                 pm = json.load(open(cands[-1]))
-                want = ("k_join_fused",)
+                want = ("k_join_spec",) if spec == 1 else ("k_join_fused",)
                 per = {}
                 for kname, kv in pm.items():
                     if isinstance(kv, dict) and any(wk in kname for wk in want) and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
@@ -637,7 +644,8 @@ def main():
                        "order": args.order, "radix_bits_used": st["radix_bits"],
                        "stage_times": ("events of the timed steps" if args.timing == 2 else
                                        "second pass of %d steps with per-stage events (the timed steps ran with timing %d)" % (stage_steps, args.timing)),
-                       "units": st["units"], "max_build_side": st["max_build"]},
+                       "units": st["units"], "max_build_side": st["max_build"],
+                       "fk_speculation": ("held" if spec == 1 else "failed: the ordinary kernel did the join" if spec == 2 else "not tried")},
             "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -167,6 +167,12 @@ void rhj_set_lowradix(int on);
  * (csrc/rhj_partition.hip.h, k_local_part); 0: a kernel of its own counts them from one byte per tuple at every width, as
  * it does at 13..15 bits.  Results are identical either way (env RHJ_NO_COUNT_IN_PASS1=1; for A/B and tests). */
 void rhj_set_count_in_pass1(int on);
+/* 1 (default): big joins first try the foreign-key speculation — every tuple of the bigger relation has exactly one match
+ * (csrc/rhj_join_fused.hip.h, k_join_spec): pairs of the units that relation probes are written without stash or chained
+ * offsets; checked on the device, and the ordinary kernel takes over in the same call when it does not hold.  Results are
+ * identical either way (env RHJ_NO_SPEC=1).  rhj_last_spec(): the last join — 0 not tried, 1 held, 2 failed. */
+void rhj_set_spec(int on);
+int  rhj_last_spec(void);
 /* Pair order (env RHJ_ORDER=canonical|any).  0 = canonical (default): the reference's order for the
  * radix width in force — bucket ascending, probe side = R iff cR >= cS, probe tuples in input order, build matches
  * in descending position (rhjoin.c:42-57,86,141-250).  1 = any: the same pairs in the canonical order of a radix

@@ -85,6 +85,10 @@ struct Ctx {
     int         timing = 2;          // 0: no events, rhj_get_stats() times are zero; 1: whole join only; 2: per stage (env RHJ_TIMING, rhj_set_timing)
     bool        stamps = false;      // env RHJ_STAMPS (diagnostics build): in-kernel phase stamps of the fused kernel, read once at load time
     int         no_count_in_pass1 = 0;   // 1: pass 2's counts from the digit bytes (k_hist_runs) at every radix width (env RHJ_NO_COUNT_IN_PASS1; A/B)
+    int         no_spec = 0;         // 1: never try the foreign-key speculation (env RHJ_NO_SPEC; rhj_set_spec(0))
+    int         spec_score = 2;      // > 0: try it (a speculation that holds adds 1, up to 4; one that fails takes 2 off)
+    int         spec_skipped = 0;    // joins not speculated on since the score went to zero: every 16th tries again
+    int         last_spec = 0;       // the last join: 0 not tried, 1 held, 2 failed (rhj_last_spec)
     int         seen_wide = 0;       // a join of this process needed 16-byte intermediates: launch those kernels from now on
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
@@ -133,6 +137,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NODE_PAIRS"))) g.node_pairs = strtoull(e, nullptr, 10);
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
         if ((e = getenv("RHJ_NO_LOWRADIX"))) g.no_lowradix = atoi(e);
+        if ((e = getenv("RHJ_NO_SPEC"))) g.no_spec = atoi(e);
         if ((e = getenv("RHJ_NO_COUNT_IN_PASS1"))) g.no_count_in_pass1 = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
@@ -186,8 +191,9 @@ int ctx_init()
     // dynamic LDS above 64 KiB has to be requested per kernel
     HIP_TRY(hipFuncSetAttribute((const void *)k_build_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     {
-        const void *fused[4] = {(const void *)k_join_fused<false, false>, (const void *)k_join_fused<false, true>,
-                                (const void *)k_join_fused<true, false>, (const void *)k_join_fused<true, true>};
+        const void *fused[6] = {(const void *)k_join_fused<false, false>, (const void *)k_join_fused<false, true>,
+                                (const void *)k_join_fused<true, false>, (const void *)k_join_fused<true, true>,
+                                (const void *)k_join_spec<false>, (const void *)k_join_spec<true>};
         for (const void *k : fused)
             HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
         HIP_TRY(hipFuncSetAttribute((const void *)k_join_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
@@ -557,7 +563,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.pad = 0;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.spec = 0; fa.pad = 0;
         fa.unit_bound = unit_bound;
         fa.host_summary = (uint64_t *)g.pin;
         fa.dbg = nullptr;
@@ -663,7 +669,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;               // words 0..7 hold the ticket
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.pad = 0;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.spec = 0; fa.pad = 0;
         fa.unit_bound = unit_bound;
         fa.host_summary = nullptr;
         fa.dbg = nullptr;
@@ -694,6 +700,20 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             // partition's 16-byte kernels were (one-pass partitions, forced-wide runs, a process that has seen wide row ids).
             const bool maybe_narrow = bits > PT_MAX_BITS && !force_wide;
             const bool maybe_wide = !maybe_narrow || ps.launch_wide;
+            // The foreign-key speculation (k_join_spec): the bigger relation's tuples have one match each?  Then nothing is
+            // stashed for the units that relation probes and nothing is chained.  Tried while it keeps holding; a failed try
+            // costs the time to the first unit that notices (tens of microseconds), so after failures only every 16th join tries.
+            bool try_spec = attempt == 0 && maybe_narrow && out != nullptr && g.no_spec <= 0 && !g.ablate &&
+                            out_capacity >= (nS >= nR ? nS : nR);
+            if (try_spec && g.spec_score <= 0 && g.no_spec >= 0 && ++g.spec_skipped < 16) try_spec = false;   // (RHJ_NO_SPEC=-1: always try — to time a failing one)
+            fa.spec = try_spec ? (nS >= nR ? 1u : 2u) : 0u;
+            if (try_spec) {
+                g.spec_skipped = 0;
+                if (nmin / bins <= 7000 && !g.no_resident)
+                    RHJ_LAUNCH((k_join_spec<true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                else
+                    RHJ_LAUNCH((k_join_spec<false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+            }
             if (nmin / bins <= 7000 && !g.no_resident) {
                 if (maybe_narrow)
                     RHJ_LAUNCH((k_join_fused<true, true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
@@ -708,9 +728,18 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             RHJ_LAUNCH(k_join_walk, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);   // returns at once when no unit needs it
             RHJ_STAGE(ST_END);
             HIP_TRY(hipMemcpyAsync(hs, g.summary.p, sizeof(PlanSummary), hipMemcpyDeviceToHost, g.stream));
+            uint32_t *spec_words = (uint32_t *)((char *)g.pin + 512);       // the ticket words: word 4 = the speculation failed
+            if (try_spec) HIP_TRY(hipMemcpyAsync(spec_words, g.status.p, 32, hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;
+            g.last_spec = 0;
+            if (try_spec) {
+                const bool held = spec_words[4] == 0;
+                g.last_spec = held ? 1 : 2;
+                g.spec_score = held ? (g.spec_score < 4 ? g.spec_score + 1 : 4) : g.spec_score - 2;
+                if (g.spec_score < -2) g.spec_score = -2;
+            }
             if (plan.row_id_overflow) { *overflow = true; return 0; }     // (also: wide row ids met the 12-byte kernels alone)
             if (plan.fused_ok && plan.matches == FJ_NO_TOTAL && !g.ablate) { fprintf(stderr, "rhj: fused join left no match total (chained scan incomplete)\n"); return -1; }
             if (!plan.fused_ok) {
@@ -880,7 +909,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     FusedArgs fa;
     fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
     fa.status = (uint64_t *)g.status.p + 8; fa.ticket = (uint32_t *)g.status.p;
-    fa.nR = nR; fa.allow_resident = 0; fa.radix_bits = (uint32_t)T; fa.lr_mode = 1; fa.pad = 0;
+    fa.nR = nR; fa.allow_resident = 0; fa.radix_bits = (uint32_t)T; fa.lr_mode = 1; fa.spec = 0; fa.pad = 0;
     fa.unit_bound = unit_bound; fa.host_summary = nullptr; fa.dbg = nullptr;
     fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p; fa.walk = (FjWalkItem *)g.walk.p;
     const uint32_t fused_lds = LDS_BUDGET - FJ_LDS_EXTRA;
@@ -1123,6 +1152,8 @@ void rhj_set_fused(int on) { g.no_fused = !on; g.force_fused = on >= 2; }
 void rhj_set_resident(int on) { g.no_resident = !on; }
 void rhj_set_small(int on) { g.no_small = !on; }
 void rhj_set_lowradix(int on) { g.no_lowradix = !on; }
+void rhj_set_spec(int on) { g.no_spec = !on; g.spec_score = 2; g.spec_skipped = 0; }
+int rhj_last_spec(void) { return g.last_spec; }
 void rhj_set_count_in_pass1(int on) { g.no_count_in_pass1 = !on; }
 void rhj_set_order(int any) { g.order_any = any != 0; }
 int rhj_auto_radix_bits(uint64_t nR, uint64_t nS) { return auto_radix_bits(nR, nS); }

@@ -51,12 +51,14 @@ struct FusedArgs {
     uint64_t *stash_row;      // [nR + nS] build row id of the first match
     uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
     uint32_t *ticket;         // word 0: next unit; word 1: workgroups that are through (the last one out leaves the match total);
-                              // word 2: entries of the walk list; word 3: k_join_walk's own ticket
+                              // word 2: entries of the walk list; word 3: k_join_walk's own ticket; word 4: the foreign-key
+                              // speculation failed (k_join_spec); words 6..7 (one u64): the totals it predicted, summed
     uint64_t  nR;
     uint32_t  allow_resident;
     uint32_t  radix_bits;     // the join's radix width (the bits every key of a bucket shares)
     uint32_t  lr_mode;        // low-radix path (rhj_lowradix.hip.h): a tuple with several matches leaves the place of its pairs in its stash row
-    uint32_t  pad;
+    uint32_t  spec;           // foreign-key speculation (k_join_spec, below): 0 none, 1 every S tuple has exactly one match, 2 every R tuple
+    uint64_t  pad;
     uint64_t  unit_bound;     // status words there are
     uint64_t *host_summary;   // pinned host block that receives the plan summary (with the match total) at the end, or null
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
@@ -915,7 +917,15 @@ __device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, con
 #endif
 // The whole body is a device function: k_join_fused runs it over units a host-launched plan wrote, k_small_join
 // (rhj_small.hip.h) as the last phase of its single launch.
-template <bool MAYRES, bool N32>
+// SPEC (k_join_spec): the FOREIGN-KEY SPECULATION.  Hypothesis: every tuple of one relation (f.spec: 1 = S, 2 = R) has exactly
+// one match.  Then the join's pairs of bucket b start at that relation's psum[b] and number its hist[b], whichever side
+// probes: nothing is chained.  A unit whose probe side IS that relation writes its pairs straight from phase 1 — pair i of
+// the unit at base + i, no stash, no emit pass — and checks that every tuple had exactly one match; a unit whose probe side
+// is the other relation runs as usual, but emits at once at the predicted base and checks its total (such a bucket must be
+// one unit).  Any check that fails raises ticket[4], the workgroups stop, and the ordinary kernel, always enqueued behind
+// this one, does the join (it returns at once when the speculation held).  The last workgroup out also checks that the
+// predicted totals add up to the relation's size (a bucket without partners has no unit to notice it).
+template <bool MAYRES, bool N32, bool SPEC = false>
 __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
@@ -941,7 +951,11 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 
     for (uint32_t iter = 0;; ++iter) {
     __syncthreads();
-    if (threadIdx.x == 0) { sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; sh_grab = 0; sh_patch = 0; }
+    if (threadIdx.x == 0) {
+        sh_u = atomicAdd(f.ticket, 1u); sh_ovf = 0; sh_grab = 0; sh_patch = 0;
+        // (SPEC: a failed check anywhere ends the kernel — one thread reads the word, so the whole workgroup agrees)
+        if (SPEC && __hip_atomic_load(f.ticket + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) sh_u = 0xffffffffu;
+    }
     __syncthreads();
     const uint32_t u = sh_u;
     if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
@@ -950,6 +964,12 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     const uint64_t cR = a.histR[b], cS = a.histS[b];
     const bool flip = bucket_flip(a, b, cR, cS);                       // S is streamed (r_s == 1)
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;   // position in the probe relation
+    // SPEC: the probe side is the relation of the hypothesis (fkp); the unit's predicted first pair and pair count
+    const bool fkp = SPEC && (flip == (f.spec == 1u));
+    const uint64_t spec_base = SPEC ? (f.spec == 1u ? a.psumS[b] : a.psumR[b]) + (fkp ? un.off : 0u) : 0u;
+    const uint64_t spec_total = SPEC ? (fkp ? (uint64_t)un.count : (f.spec == 1u ? cS : cR)) : 0u;
+    bool spec_bad = SPEC && !fkp && (un.off != 0 || un.count != (flip ? cS : cR));   // (a split bucket's later units cannot know their base)
+    if (SPEC && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(f.ticket + 6), (unsigned long long)spec_total);
     const rhj_tuple *prp = flip ? a.partS : a.partR;                   // probe tuple i of the unit: pt_load<N32>(prp, ppos + i)
     const rhj_tuple *bdp = flip ? a.partR : a.partS;                   // build tuple i of the bucket: pt_load<N32>(bdp, bpos + i)
     const uint64_t bpos = flip ? a.psumR[b] : a.psumS[b];
@@ -1015,6 +1035,26 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         uint32_t run[FJ_V], bm[FJ_V];
         if (RES) fj_count_res(X, ltup, q, okk, c, flo, fhi, fp, run);
         else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, bm, O);
+        // (The failure word is looked at once a unit, not here: an agent-scope load a group made every wave wait for its
+        // outstanding pair stores and gathers — the kernel was 18 % slower than without the speculation.  A failing
+        // speculation costs 0.15 ms that way instead of 0.07, and after one that failed only every 16th join tries.)
+        if (SPEC && fkp) {                             // one match each, or the speculation is off: the pairs go out right here
+#pragma unroll
+            for (int k = 0; k < FJ_V; ++k) {
+                const uint32_t i = t0 + k * WAVE + lane;
+                if (i < un.count) {
+                    spec_bad = spec_bad || c[k] != 1u;
+                    const uint64_t at = spec_base + i;
+                    if (at < a.out_capacity) out[at] = make_pair(flip, q[k].z, N32 ? 0u : q[k].w, flo[k], fhi[k]);
+                }
+            }
+            if (__ballot(spec_bad) != 0) {            // noticed at once, and by everybody
+                if (lane == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                spec_bad = true;
+                break;
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + k * WAVE + lane;
@@ -1043,6 +1083,13 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         }
     }
 
+    if (SPEC) {                                       // a check failed (here or in another workgroup): stop
+        if (__syncthreads_or(spec_bad)) {
+            if (threadIdx.x == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (fkp) continue;                            // the pairs are out, one match each
+    }
     // ---- unit total -> chained scan
     if (FJ_DBG && lane == 0) { if (w == 0) FJ_DBG[(size_t)u * 8 + 2] = __builtin_amdgcn_s_memrealtime(); }
     {
@@ -1057,7 +1104,20 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     uint64_t total = 0;
 #pragma unroll
     for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
-    if (threadIdx.x == 0) {
+    if (SPEC) {                                       // the other relation probes: the usual unit at the predicted base, emitted at once
+        if (total != spec_total) {                    // (workgroup-uniform)
+            if (threadIdx.x == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (threadIdx.x == 0) { a.unit_count[u] = total; sh_base = spec_base; }
+        __syncthreads();
+        if (!emitting) continue;
+        if (!unit_needs_index && !unit_res_dup) {
+            if (ovf_total != 0) fj_emit_stream<true, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, MAYRES ? 0u : npatch);
+            else                fj_emit_stream<false, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, 0u);
+            continue;
+        }
+    } else if (threadIdx.x == 0) {
         // aggregate first: successors only ever wait for this word
         __hip_atomic_store(&st[u], ((u == 0 ? 2ull : 1ull) << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.unit_count[u] = total;
@@ -1081,7 +1141,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         __syncthreads();
         if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     }
-    if (emitting && !unit_needs_index && !unit_res_dup) {   // this unit's emit pass needs no index: defer it
+    if (!SPEC && emitting && !unit_needs_index && !unit_res_dup) {   // this unit's emit pass needs no index: defer it
         pend = u;
         pend_total = total;
         pend_dup = ovf_total != 0;
@@ -1092,14 +1152,16 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         continue;
     }
 
-    if (w == 0) {
-        const uint64_t excl = u == 0 ? 0 : fj_lookback(st, u, lane);
-        if (lane == 0) {
-            if (u != 0) __hip_atomic_store(&st[u], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_base = excl;
+    if (!SPEC) {
+        if (w == 0) {
+            const uint64_t excl = u == 0 ? 0 : fj_lookback(st, u, lane);
+            if (lane == 0) {
+                if (u != 0) __hip_atomic_store(&st[u], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_base = excl;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     if (!emitting) continue;
@@ -1131,9 +1193,35 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     }
 }
 
+// The speculative kernel (fj_body<., ., SPEC>), 12-byte tuples only; always followed by k_join_fused with the same arguments.
+template <bool MAYRES>
+__global__ __launch_bounds__(FJ_BLOCK) void k_join_spec(FusedArgs f, uint32_t lds_bytes)
+{
+    fj_body<MAYRES, true, true>(f, lds_bytes);
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(f.ticket + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {   // the last workgroup out
+        __hip_atomic_store(f.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long predicted =
+            __hip_atomic_load(reinterpret_cast<unsigned long long *>(f.ticket + 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the relation's tuples that take part (all of them, unless the join is one rank's share of a sharded join)
+        const uint32_t last = (1u << f.radix_bits) - 1u;
+        const uint64_t n_fk = f.spec == 1u ? f.j.psumS[last] + f.j.histS[last] : f.j.psumR[last] + f.j.histR[last];
+        bool failed = __hip_atomic_load(f.ticket + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || predicted != n_fk;
+        if (failed) {                                 // the ordinary kernel behind this one starts over
+            __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(f.ticket + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(f.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
+            const_cast<PlanSummary *>(f.j.summary)->matches = n_fk;
+    }
+}
+
 template <bool MAYRES, bool N32>
 __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t lds_bytes)
 {
+    // behind k_join_spec: nothing to do when its speculation held (every workgroup reads the same word: all leave or none)
+    if (f.spec && __hip_atomic_load(f.ticket + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     fj_body<MAYRES, N32>(f, lds_bytes);
     // The last workgroup out leaves the match total = inclusive prefix of the last unit (every unit publishes one
     // before it emits; nothing when the plan rejected the fused path: its unit list is the tiled one then).  Both

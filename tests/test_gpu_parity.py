@@ -172,6 +172,40 @@ def test_partition_counts_from_digit_bytes_match_the_counts_of_pass_1(rhj, oracl
         rhj.lib.rhj_set_count_in_pass1(1)
 
 
+def test_foreign_key_speculation_holds_or_hands_over(rhj, oracle):
+    """Big joins first run k_join_spec on the hypothesis that every tuple of the bigger relation has exactly one match
+    (pairs written without stash or chained offsets); one tuple that breaks it — no partner, two partners, on either side —
+    and the ordinary kernel does the join in the same call.  Identical pairs in every case; rhj_last_spec() says which way it went."""
+    rhj.set_bits(12)
+    set_path(rhj, "fused")
+    nR, nS = 400_000, 700_000
+    R = oracle.generate(nR, 0, 0, 0.0, 91)                       # unique keys 0..nR-1
+    S = oracle.generate(nS, 1, nR, 0.0, 92)                      # every S key has its R tuple
+    def run(R, S, expect):
+        rhj.lib.rhj_set_spec(1)                                  # (also resets the try-or-not score)
+        want = oracle.join(R, S, 12)
+        t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), capacity=max(len(R), len(S)) + 16)   # (room for the prediction)
+        got = rhj.pairs_to_numpy(t)
+        assert m == len(want) and len(got) == len(want) and (got == want).all()
+        assert rhj.lib.rhj_last_spec() == expect, (rhj.lib.rhj_last_spec(), expect)
+    try:
+        run(R, S, 1)                                             # S is the foreign-key side
+        run(S, R, 1)                                             # ... and as the first argument (hypothesis on R)
+        S2 = S.copy(); S2["value"][nS // 2] = np.uint64(1 << 50)   # one S tuple without a partner
+        run(R, S2, 2)
+        R2 = R.copy(); R2["value"][nR // 3] = R2["value"][nR // 3 + 1]   # one R key twice (and one missing)
+        run(R2, S, 2)
+        run(S2, R, 2)
+        Rb = oracle.generate(nS + 5, 0, 0, 0.0, 93)              # R bigger than S: the hypothesis is on R, whose tuples match 0..k times
+        run(Rb, S, 2)
+        rhj.lib.rhj_set_spec(0)
+        want = oracle.join(R, S, 12)
+        got = dev_join(rhj, R, S)
+        assert (got == want).all() and rhj.lib.rhj_last_spec() == 0
+    finally:
+        rhj.lib.rhj_set_spec(1)
+
+
 def test_row_id_width_is_speculated_and_a_wrong_guess_runs_again():
     """The 16-byte kernels of the two-pass partition are not launched until a join of the process has needed them: the first
     join with wide row ids is reported as an overflow by the sample and run again wide; later joins launch both widths."""
