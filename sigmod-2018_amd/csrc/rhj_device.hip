@@ -704,7 +704,8 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             // stashed for the units that relation probes and nothing is chained.  Tried while it keeps holding; a failed try
             // costs the time to the first unit that notices (tens of microseconds), so after failures only every 16th join tries.
             bool try_spec = attempt == 0 && maybe_narrow && out != nullptr && g.no_spec <= 0 && !g.ablate &&
-                            out_capacity >= (nS >= nR ? nS : nR);
+                            out_capacity >= (nS >= nR ? nS : nR) &&
+                            (nS >= nR ? nS : nR) / bins >= 4096;     // (units of 2.4 K tuples: 10M x 10M at 12 bits lost 7 % to its per-unit extras)
             if (try_spec && g.spec_score <= 0 && g.no_spec >= 0 && ++g.spec_skipped < 16) try_spec = false;   // (RHJ_NO_SPEC=-1: always try — to time a failing one)
             fa.spec = try_spec ? (nS >= nR ? 1u : 2u) : 0u;
             if (try_spec) {

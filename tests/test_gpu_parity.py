@@ -176,14 +176,14 @@ def test_foreign_key_speculation_holds_or_hands_over(rhj, oracle):
     """Big joins first run k_join_spec on the hypothesis that every tuple of the bigger relation has exactly one match
     (pairs written without stash or chained offsets); one tuple that breaks it — no partner, two partners, on either side —
     and the ordinary kernel does the join in the same call.  Identical pairs in every case; rhj_last_spec() says which way it went."""
-    rhj.set_bits(12)
+    rhj.set_bits(9)                                              # (the speculation wants 4096 tuples of the bigger relation a bucket)
     set_path(rhj, "fused")
-    nR, nS = 400_000, 700_000
+    nR, nS = 1_200_000, 2_200_000
     R = oracle.generate(nR, 0, 0, 0.0, 91)                       # unique keys 0..nR-1
     S = oracle.generate(nS, 1, nR, 0.0, 92)                      # every S key has its R tuple
     def run(R, S, expect):
         rhj.lib.rhj_set_spec(1)                                  # (also resets the try-or-not score)
-        want = oracle.join(R, S, 12)
+        want = oracle.join(R, S, 9)
         t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), capacity=max(len(R), len(S)) + 16)   # (room for the prediction)
         got = rhj.pairs_to_numpy(t)
         assert m == len(want) and len(got) == len(want) and (got == want).all()
@@ -199,7 +199,7 @@ def test_foreign_key_speculation_holds_or_hands_over(rhj, oracle):
         Rb = oracle.generate(nS + 5, 0, 0, 0.0, 93)              # R bigger than S: the hypothesis is on R, whose tuples match 0..k times
         run(Rb, S, 2)
         rhj.lib.rhj_set_spec(0)
-        want = oracle.join(R, S, 12)
+        want = oracle.join(R, S, 9)
         got = dev_join(rhj, R, S)
         assert (got == want).all() and rhj.lib.rhj_last_spec() == 0
     finally:
