@@ -222,7 +222,6 @@ struct PartState {
     RelArgs  p2[2];          // two-pass partition: the relations as pass 2 saw them (runs, digit bytes, scanned tile counts) —
                              // the low-radix path replays pass 2's order when it emits (rhj_lowradix.hip.h)
     int      lo_bits = 0;    // two-pass partition: digit bits of pass 1 (0: half of the radix); the low-radix path passes the caller's radix
-    uint32_t *big_tile = nullptr;   // device word that k_hist_runs raises when a pass-2 tile exceeds one batch (or null)
     RelArgs  r[2];           // in = caller's input, out = final partitioned array
     rhj_tuple *tmp[2];       // intermediate of the two-pass path
     uint64_t *hist, *psum;   // [2][bins] of the join's radix (filled by run_partition)
@@ -871,7 +870,6 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     ps.lo_bits = r;                                            // pass 1 on exactly the caller's bits: pass 2 reads in canonical order
     uint32_t *words = (uint32_t *)g.lr_words.p;                // word 0: a pass-2 tile / chunk beyond one batch; word 1: k_lr_emit's ticket
     uint8_t *parent_flip = (uint8_t *)(words + 16);            // [2 << r]
-    ps.big_tile = nullptr;                                     // (a pass-2 tile of several batches is walked batch by batch)
     HIP_TRY(hipMemsetAsync(words, 0, 64, g.stream));
     if (run_partition(ps, T, 2, false, true)) return -1;
     RHJ_STAGE(ST_PLAN);

@@ -461,26 +461,6 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
             uint32_t phys, len;
             pt_run_of(r, tile2, c0 + lane, phys, len);
             const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
-#ifdef HR_BYTE_LOADS      // the first form: one run per wave load, a byte per lane (kept for A/B)
-            for (uint32_t q0 = 0; q0 < nrun; q0 += 16) {
-                uint32_t dg[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)phys, (int)((q0 + q) & 63u));
-                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)((q0 + q) & 63u));
-                    dg[q] = (q0 + q < nrun && lane < l) ? r.dig_in[p + lane] : 0xffffffffu;
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (dg[q] != 0xffffffffu) atomicAdd(&h[dg[q]], 1u);
-                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)((q0 + q) & 63u));
-                    if (q0 + q < nrun && l > WAVE) {          // skewed keys: a run longer than one load
-                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)phys, (int)((q0 + q) & 63u));
-                        for (uint32_t e = lane + WAVE; e < l; e += WAVE) atomicAdd(&h[r.dig_in[p + e]], 1u);
-                    }
-                }
-            }
-#else
             // four runs per wave load: sixteen lanes a run, four digit bytes a lane (the digit array is padded by 64 bytes,
             // a run's last dword may reach past its end: those bytes are not counted); eight loads in flight
             const uint32_t g4 = lane >> 4, sub4 = (lane & 15u) * 4u;
@@ -508,7 +488,6 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
                     }
                 }
             }
-#endif
         }
         uint32_t *row = r.cnt + (size_t)tile2 * bins;
         for (uint32_t b = lane; b < bins; b += WAVE) row[b] = h[b];
