@@ -567,6 +567,24 @@ def main():
         elapsed = float(t.item())
     st = rhj.stats()
     stage = {k: acc[k] / stage_steps for k in keys}
+    spec_state = int(rhj.lib.rhj_last_spec())           # the timed steps' last join: 0 not tried, 1 the speculation held, 2 failed
+    nospec = None
+    if spec_state == 1:
+        # For the record, behind the timed region: the same steps with the foreign-key speculation switched off
+        #  — identical pairs from the general kernel alone.
+        rhj.lib.rhj_set_spec(0)
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pm = 0.0
+        for _ in range(args.steps):
+            step()
+            pm += rhj.stats()["ms_probe"]
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        rhj.lib.rhj_set_spec(1)
+        nospec = {"ms_per_step": e1 / args.steps * 1e3, "value": w["nS"] * args.steps / e1 / 1e9, "probe_kernel": "k_join_fused",
+                  "probe_ms": pm / args.steps, "note": "rank 0's own clock, not barriered; same inputs, same pairs"}
 
     if rank == 0:
         nR, nS, M = w["nR"], w["nS"], m.value
@@ -600,7 +618,7 @@ def main():
         fused = st["path"] in ("fused", "small")
         lowradix = st["path"] == "lowradix"
         join_ms = stage["ms_build"] + stage["ms_count"] + stage["ms_offsets"] + stage["ms_probe"]
-        spec = int(rhj.lib.rhj_last_spec()) if fused and not small else 0      # 0 not tried, 1 the foreign-key speculation held, 2 failed
+        spec = spec_state if fused and not small else 0
         probe_kernel = ("k_join_spec (the fused join kernel on the foreign-key speculation, which held: LDS index build + probe, pairs of the "
                         "foreign-key side's units written from the probe loop, no stash, no chained offsets; k_join_fused and k_join_walk "
                         "behind it return at once)" if fused and spec == 1
@@ -645,7 +663,8 @@ def main():
                        "stage_times": ("events of the timed steps" if args.timing == 2 else
                                        "second pass of %d steps with per-stage events (the timed steps ran with timing %d)" % (stage_steps, args.timing)),
                        "units": st["units"], "max_build_side": st["max_build"],
-                       "fk_speculation": ("held" if spec == 1 else "failed: the ordinary kernel did the join" if spec == 2 else "not tried")},
+                       "fk_speculation": ("held" if spec == 1 else "failed: the ordinary kernel did the join" if spec == 2 else "not tried"),
+                       "without_fk_speculation": nospec},
             "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -89,6 +89,7 @@ struct Ctx {
     int         spec_score = 2;      // > 0: try it (a speculation that holds adds 1, up to 4; one that fails takes 2 off)
     int         spec_skipped = 0;    // joins not speculated on since the score went to zero: every 16th tries again
     int         last_spec = 0;       // the last join: 0 not tried, 1 held, 2 failed (rhj_last_spec)
+    int         lo_override = 0;     // RHJ_LO_BITS: pass-1 digit bits of the two-pass partition (experiments; default bits / 2)
     int         seen_wide = 0;       // a join of this process needed 16-byte intermediates: launch those kernels from now on
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
@@ -138,6 +139,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
         if ((e = getenv("RHJ_NO_LOWRADIX"))) g.no_lowradix = atoi(e);
         if ((e = getenv("RHJ_NO_SPEC"))) g.no_spec = atoi(e);
+        if ((e = getenv("RHJ_LO_BITS"))) g.lo_override = atoi(e);
         if ((e = getenv("RHJ_NO_COUNT_IN_PASS1"))) g.no_count_in_pass1 = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
@@ -320,7 +322,9 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     }
 
     // ---- two passes in run form (k_local_part .. k_scatter_runs in rhj_kernels.hip.h)
-    const int lo = ps.lo_bits ? ps.lo_bits : bits / 2, hi = bits - lo;
+    int lo = ps.lo_bits ? ps.lo_bits : bits / 2;
+    if (!ps.lo_bits && g.lo_override > 0 && g.lo_override < bits && bits - g.lo_override <= PT_MAX_BITS && g.lo_override <= PT_MAX_BITS) lo = g.lo_override;   // (RHJ_LO_BITS: experiments)
+    const int hi = bits - lo;
     const uint32_t bins1 = 1u << lo, bins2 = 1u << hi;
     if (ensure(g.slice_tot, (size_t)2 * bins * FH_SLICES * 4) || ensure(g.sbase, (size_t)2 * bins * FH_SLICES * 4)) return -1;
     RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
