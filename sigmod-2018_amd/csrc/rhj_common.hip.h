@@ -28,8 +28,10 @@ struct RelArgs {                 // one relation through one partition pass
     // pass 1 counting pass 2's digits itself (radix bits <= 12): a workgroup walks a STRIP of PT_STRIP pass-1 tiles of one
     // group and leaves its (pass-1 digit, pass-2 digit) counts, 16 bits each: part[d][strip][digit], strip = group * parts + p
     uint16_t        *part;
-    uint32_t         parts;      // strips per group = ceil(group / PT_STRIP)
+    uint32_t         parts;      // strips per group = ceil(group / strip)
     uint32_t         per;        // groups per scan slice = ceil(groups / FH_SLICES)
+    uint32_t         strip;      // pass-1 tiles a strip (1..PT_STRIP: fewer for small relations, whose strips would not fill the chip)
+    uint32_t         pad;
     // pass 2's start offsets come in two parts: cnt[tile (d, j)][digit] = the tuples of (d, digit) in groups of j's slice in
     // front of j, sbase[d][slice][digit] = where that slice starts in the output (bucket start + the slices in front of it)
     uint32_t        *sbase;

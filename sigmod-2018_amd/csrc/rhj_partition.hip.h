@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void k_rowid_sample(RelArgs r0, RelArgs r1, i
 #ifndef PT_STRIP_N
 #define PT_STRIP_N 4
 #endif
-constexpr uint32_t PT_STRIP = PT_STRIP_N;           // (16-bit cells: a strip may hold at most 15 tiles)
+constexpr uint32_t PT_STRIP = PT_STRIP_N;           // tiles a strip, at most (16-bit cells: 15 is the limit; RelArgs::strip: fewer for small inputs)
 template <bool RANGED, bool H2, bool DIG>
 __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
                                                          PlanSummary *summary, uint32_t h2_off)
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     if (H2) {
         const uint32_t strip = blockIdx.x, j = strip / r.parts, p = strip - j * r.parts;
         if (j >= r.groups) return;
-        tile = j * r.group + p * PT_STRIP;
-        tile_end = min(min(tile + PT_STRIP, (j + 1) * r.group), r.tiles);
+        tile = j * r.group + p * r.strip;
+        tile_end = min(min(tile + r.strip, (j + 1) * r.group), r.tiles);
         for (uint32_t i = threadIdx.x; i < (1u << (bits + next_bits - 1)); i += PT_BLOCK) h2[i] = 0;
     } else if (tile >= r.tiles) return;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
