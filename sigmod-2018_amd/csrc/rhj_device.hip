@@ -408,8 +408,8 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
                    b0, b1, hi);
         RHJ_LAUNCH((k_group_scan<false>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p);
     }
-    const int staged = bits >= 13 && bits <= 14;      // (15 bits: 256 KiB of totals do not fit LDS)
-#define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), staged ? (size_t)bins * 8 : 0, g.stream, lo, hi, \
+    const int staged = bits >= 13;
+#define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), staged ? (size_t)(bins < 16384u ? bins : 16384u) * 8 : 0, g.stream, lo, hi, \
                             (const uint32_t *)g.slice_tot.p, (uint32_t *)g.sbase.p, ps.hist, ps.psum, staged)
     if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else RHJ_BP(0);
 #undef RHJ_BP

@@ -646,26 +646,36 @@ __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const
     }
     // Any count.  A thread's buckets are consecutive (the scan wants them so), which makes its loads of the slice totals
     // 64-byte-strided over the wave: 0.13 ms for 16 K buckets.  `staged`: the workgroup first reads all totals coalesced and
-    // leaves every bucket's total and the sum of the slices in front of its own in LDS (2 x 4 bytes a bucket: up to 14 bits).
+    // leaves every bucket's total and the sum of the slices in front of its own in LDS (2 x 4 bytes a bucket).
     extern __shared__ uint32_t lds_bp[];
-    uint32_t *tl = lds_bp, *fl = lds_bp + all_bins;
-    if (staged) {
-        for (uint32_t bk = threadIdx.x; bk < all_bins; bk += 1024u) {
-            uint32_t c[FH_SLICES], t = 0, front = 0;
+    uint32_t *tl = lds_bp;
+    if (staged) {                                     // 16 K buckets a round (2 x 64 KiB of LDS): 15 bits take two
+        const uint32_t chunk = min(all_bins, 16384u), cper = chunk / 1024u;
+        uint32_t *fl2 = lds_bp + chunk;
+        uint64_t carry = 0;
+        for (uint32_t c0 = 0; c0 < all_bins; c0 += chunk) {
+            for (uint32_t i = threadIdx.x; i < chunk; i += 1024u) {
+                const uint32_t bk = c0 + i;
+                uint32_t c[FH_SLICES], t = 0, front = 0;
 #pragma unroll
-            for (uint32_t z = 0; z < FH_SLICES; ++z) c[z] = st[(size_t)z * all_bins + bk];
+                for (uint32_t z = 0; z < FH_SLICES; ++z) c[z] = st[(size_t)z * all_bins + bk];
 #pragma unroll
-            for (uint32_t z = 0; z < FH_SLICES; ++z) { front += z < zme ? c[z] : 0u; t += c[z]; }
-            tl[bk] = t; fl[bk] = front;
-        }
-        __syncthreads();
-        for (uint32_t bk = b0; bk < b1; ++bk) mine += tl[bk];
-        uint64_t base = block_excl_scan<1024>(mine, nullptr, sm);
-        for (uint32_t bk = b0; bk < b1; ++bk) {
-            const uint32_t t = tl[bk];
-            if (zme == 0) { h[bk] = t; p[bk] = base; }
-            sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + fl[bk];
-            base += t;
+                for (uint32_t z = 0; z < FH_SLICES; ++z) { front += z < zme ? c[z] : 0u; t += c[z]; }
+                tl[i] = t; fl2[i] = front;
+            }
+            __syncthreads();
+            const uint32_t i0 = threadIdx.x * cper;
+            uint64_t sum = 0, all = 0;
+            for (uint32_t i = i0; i < i0 + cper; ++i) sum += tl[i];
+            uint64_t base = carry + block_excl_scan<1024>(sum, &all, sm);
+            for (uint32_t i = i0; i < i0 + cper; ++i) {
+                const uint32_t bk = c0 + i, t = tl[i];
+                if (zme == 0) { h[bk] = t; p[bk] = base; }
+                sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + fl2[i];
+                base += t;
+            }
+            carry += all;
+            __syncthreads();
         }
         return;
     }
