@@ -114,6 +114,8 @@ int rhj_gather_tables_device(uint64_t *const *dst, const uint64_t *const *src, i
 int rhj_build_relation_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, rhj_tuple *d_tuples);
 /* wrap-around sum of col[sel[i]] (sel may be NULL) */
 int rhj_sum_gather_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, uint64_t *sum);
+/* up to 8 such sums in one launch (CalculateQueryResults: all views of a query) */
+int rhj_sum_views_device(int views, const uint64_t *const *d_cols, const uint64_t *const *d_sels, const uint64_t *ns, uint64_t *sums);
 /* ascending i with colA[selA ? selA[i] : i] == colB[selB ? selB[i] : i] */
 int rhj_filter_eq2_device(const uint64_t *d_colA, const uint64_t *d_selA, const uint64_t *d_colB, const uint64_t *d_selB,
                           uint64_t n, uint64_t *d_out, uint64_t *hits);

@@ -36,7 +36,7 @@ INTER_SYMBOLS = [
     "InitInterData", "FreeInterData", "InitInterResults", "PrintInterResults", "FreeInterResults",
     "InsertJoinToInterResults", "GetRelation", "ScanInterResults", "SelfJoin", "MergeInterNodes", "Merge",
     "CalculateQueryResults", "PrintNullResults", "AreActiveInInter", "JoinInterNode", "CartesianInterResults",
-    "InsertSingleRowIdsToInterResult", "rhj_gather_tables_device", "rhj_build_relation_device", "rhj_sum_gather_device",
+    "InsertSingleRowIdsToInterResult", "rhj_gather_tables_device", "rhj_build_relation_device", "rhj_sum_gather_device", "rhj_sum_views_device",
     "rhj_filter_eq2_device", "rhj_resident_relation", "rhj_resident_result", "rhj_resident_inter",
     "InitRelationMap", "FreeRelationMap", "PrintRelationMap", "rhj_column_stats_device",
 ]

@@ -111,6 +111,21 @@ def test_build_relation_sum_and_eq2(rhj, mod):
     assert lib.rhj_sum_gather_device(dbig.data_ptr(), None, rows, C.byref(s)) == 0
     assert s.value == int(big.sum(dtype=np.uint64))
 
+    # all view sums of a query in one launch (CalculateQueryResults): several (column, row-id list) pairs at once, call after call
+    # (the device words and the ticket must be back at zero every time), one view, eight views, an empty list
+    lib.rhj_sum_views_device.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p, u64p]
+    views = [(dbig, dsA, n, int(big[selA].sum(dtype=np.uint64))), (dbig, None, rows, int(big.sum(dtype=np.uint64))),
+             (dA, dsB, n, int(colA[selB].sum(dtype=np.uint64))), (dB, dsA, 0, 0), (dB, None, 7, int(colB[:7].sum(dtype=np.uint64)))]
+    for take in ([0], [0, 1, 2, 3, 4], [1], [4, 3, 2, 1, 0, 0, 1, 2], [3]):
+        k = len(take)
+        cols = (C.c_void_p * k)(*[views[i][0].data_ptr() for i in take])
+        sels = (C.c_void_p * k)(*[(views[i][1].data_ptr() if views[i][1] is not None else None) for i in take])
+        ns = (C.c_uint64 * k)(*[views[i][2] for i in take])
+        got = (C.c_uint64 * k)()
+        assert lib.rhj_sum_views_device(k, cols, sels, ns, got) == 0
+        assert list(got) == [views[i][3] for i in take], take
+    assert lib.rhj_sum_views_device(9, cols, sels, ns, got) == -1        # more than eight at once: the caller splits
+
     out = torch.empty(n, dtype=torch.int64, device=rhj.dev)
     hits = C.c_uint64(0)
     for sa, sb, want in ((dsA, dsB, np.nonzero(colA[selA] == colB[selB])[0]),

@@ -11,7 +11,8 @@ for i in range(14):
     with open(os.path.join(tmp, "r%d" % i), "wb") as f:
         np.array([cols.shape[1], cols.shape[0]], dtype="<u8").tofile(f); cols.tofile(f)
     names.append("r%d" % i)
-stdin = ("\n".join(names) + "\nDone\n" + "\n".join(g.small["work_lines"]) + "\n").encode()
+REP = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # batches: the last one is analysed (steady state: workspace grown, blocks cached)
+stdin = ("\n".join(names) + "\nDone\n" + ("\n".join(g.small["work_lines"]) + "\n") * REP).encode()
 exe = os.path.abspath(os.path.join("oracle", "_ref", "radixhash_rhj_resident"))
 env = dict(os.environ, RHJ_TRACE="1", RHJ_RADIX_BITS="4")
 r = subprocess.run([exe], input=stdin, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -20,6 +21,9 @@ ts = []
 for l in lines:
     m = re.search(r"rhj-trace\s+([0-9.]+)", l)
     if m: ts.append((float(m.group(1)), l))
+if REP > 1:
+    per = (len(ts) - 15) // REP
+    ts = ts[len(ts) - per:]
 print("%d operator calls; first at %.1f ms, last at %.1f ms: %.1f ms for the queries" % (len(ts), ts[0][0], ts[-1][0], ts[-1][0] - ts[0][0]))
 ops = {}
 for (t0, l0), (t1, _) in zip(ts, ts[1:]):
