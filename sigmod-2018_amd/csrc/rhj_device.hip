@@ -1074,6 +1074,26 @@ int op_code(char op)
     return op == '<' ? 0 : op == '>' ? 1 : op == '=' ? 2 : -1;
 }
 
+// masks + tile counts -> the ascending index list and the hit total (both filters end here)
+int filter_write_out(uint64_t n, uint64_t tiles, uint64_t *total, uint64_t *d_out, uint64_t *hits)
+{
+    if (tiles <= FILTER_SELF_TILES) {                  // the write waves sum the tile counts themselves, the total lands in pinned memory:
+        RHJ_LAUNCH((k_filter_write<true>), dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,   // no scan
+                   (const uint64_t *)g.ftile.p, d_out, (unsigned long long *)g.pin);                                                  // launches, no copy
+        RHJ_STAGE(ST_END);
+    } else {
+        if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
+        RHJ_LAUNCH((k_filter_write<false>), dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
+                   (const uint64_t *)g.fbase.p, d_out, (unsigned long long *)nullptr);
+        RHJ_STAGE(ST_END);
+        HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *hits = *(volatile uint64_t *)g.pin;
+    return 0;
+}
+
 int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char op, uint64_t value, uint64_t *d_out,
                   bool use_ctx_out, uint64_t **ctx_out, uint64_t *hits)
 {
@@ -1096,14 +1116,7 @@ int filter_device(const uint64_t *d_col, const uint64_t *d_sel, uint64_t n, char
     RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_filter_mask, dim3((unsigned)tiles), dim3(256), 0, g.stream, d_col, d_sel, n, oc, value,
                        (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
-    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
-    RHJ_LAUNCH(k_filter_write, dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
-                       (const uint64_t *)g.fbase.p, d_out);
-    RHJ_STAGE(ST_END);
-    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    *hits = *(uint64_t *)g.pin;
+    if (filter_write_out(n, tiles, total, d_out, hits)) return -1;
     memset(&g.stats, 0, sizeof(g.stats));
     g.stats.n_r = n; g.stats.matches = *hits;
     g.stats.ms_total = g.stats.ms_probe = stage_ms(ST_HIST, ST_END);
@@ -1124,14 +1137,7 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
     RHJ_STAGE(ST_HIST);
     RHJ_LAUNCH(k_filter_mask_eq2, dim3((unsigned)tiles), dim3(256), 0, g.stream, colA, selA, colB, selB, n,
                (uint64_t *)g.fmask.p, (uint64_t *)g.ftile.p);
-    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
-    RHJ_LAUNCH(k_filter_write, dim3(filter_write_grid(tiles)), dim3(256), 0, g.stream, n, (const uint64_t *)g.fmask.p,
-                       (const uint64_t *)g.fbase.p, d_out);
-    RHJ_STAGE(ST_END);
-    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    *hits = *(uint64_t *)g.pin;
+    if (filter_write_out(n, tiles, total, d_out, hits)) return -1;
     memset(&g.stats, 0, sizeof(g.stats));
     g.stats.n_r = n; g.stats.matches = *hits;
     g.stats.ms_total = g.stats.ms_probe = stage_ms(ST_HIST, ST_END);

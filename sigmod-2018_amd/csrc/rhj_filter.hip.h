@@ -99,8 +99,13 @@ __global__ __launch_bounds__(256) void k_filter_mask_eq2(const uint64_t *colA, c
 // and 216 us at 1 % selectivity — 450 vector instructions per slice whatever the number of hits.)
 constexpr uint32_t FILTER_SPARSE = 1024;
 
+// SELF (at most FILTER_SELF_TILES tiles: the filters of a query workload): no scan launches — tile_base holds the tiles' COUNTS and
+// every wave sums the counts in front of its tiles itself (L2-resident, sixteen loads a lane at most); the wave of the last
+// task leaves the hit total in pinned host memory: mask + write are the filter's two launches, nothing is copied back.
+constexpr uint64_t FILTER_SELF_TILES = 1024;
+template <bool SELF>
 __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t *masks, const uint64_t *tile_base,
-                                                      uint64_t *out)
+                                                      uint64_t *out, unsigned long long *h_total)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t ntiles = (n + FILTER_TILE - 1) / FILTER_TILE;
@@ -115,7 +120,17 @@ __global__ __launch_bounds__(256) void k_filter_write(uint64_t n, const uint64_t
             const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(masks + (ebase >> 6));
             me = x.x; mo = x.y;
         }
-        const uint64_t tb = tile < ntiles ? tile_base[tile] : 0;
+        uint64_t tb = 0;
+        if (SELF) {
+            uint64_t front = 0;                       // hits of the tiles in front of this pair
+            for (uint64_t t = lane; t < 2 * task; t += WAVE) front += tile_base[t];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) front += __shfl_xor(front, d, 64);
+            const uint64_t c0 = 2 * task < ntiles ? tile_base[2 * task] : 0, c1 = 2 * task + 1 < ntiles ? tile_base[2 * task + 1] : 0;
+            tb = front + (lane >= 32 ? c0 : 0);
+            if (task == ntasks - 1 && lane == 0) __hip_atomic_store(h_total, front + c0 + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else
+            tb = tile < ntiles ? tile_base[tile] : 0;
         const uint32_t pc = (uint32_t)__popcll(me) + (uint32_t)__popcll(mo);
         if (__ballot(pc != 0) == 0) continue;
         uint32_t incl = pc;
