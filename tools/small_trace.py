@@ -31,6 +31,11 @@ for (t0, l0), (t1, _) in zip(ts, ts[1:]):
     a = ops.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += t1 - t0
 for name, (n, tot) in sorted(ops.items(), key=lambda kv: -kv[1][1]):
     print("  %-34s %4d calls  %7.2f ms in all  %6.3f ms each (until the next operator starts)" % (name, n, tot, tot / n))
+durs = sorted(((t1 - t0, l0) for (t0, l0), (t1, _) in zip(ts, ts[1:])), reverse=True)
+print("longest operators (ms until the next one starts):")
+for d, l in durs[:12]: print("   %.3f  %s" % (d, " ".join(l.split()[3:])[:110]))
+j = sorted(d for d, l in durs if "RadixHashJoin" in l)
+if j: print("RadixHashJoin: median %.3f ms, p90 %.3f, max %.3f, sum of the 10 longest %.2f ms" % (j[len(j) // 2], j[int(len(j) * 0.9)], j[-1], sum(j[-10:])))
 misses = [l for l in r.stderr.decode().splitlines() if "hipMalloc" in l and "grows" not in l]
 grows = [l for l in r.stderr.decode().splitlines() if "workspace buffer grows" in l]
 print("workspace buffers grown (hipFree + hipMalloc each): %d" % len(grows))
