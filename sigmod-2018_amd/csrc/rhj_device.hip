@@ -89,6 +89,10 @@ struct Ctx {
     int         spec_score = 2;      // > 0: try it (a speculation that holds adds 1, up to 4; one that fails takes 2 off)
     int         spec_skipped = 0;    // joins not speculated on since the score went to zero: every 16th tries again
     int         last_spec = 0;       // the last join: 0 not tried, 1 held, 2 failed (rhj_last_spec)
+    int         no_exact = 0;        // 1: never launch k_join_exact (env RHJ_NO_EXACT; rhj_set_exact(0))
+    int         exact_score = 2;     // > 0: launch it where it applies (a join it did adds 1, up to 4; one it handed back for its input takes 2 off)
+    int         exact_skipped = 0;   // eligible joins not given to it since the score went to zero: every 16th tries again
+    int         last_exact = 0;      // the last join: 0 not launched, 1 k_join_exact did the join, 2 it handed over (rhj_last_exact)
     int         lo_override = 0;     // RHJ_LO_BITS: pass-1 digit bits of the two-pass partition (experiments; default bits / 2)
     int         seen_wide = 0;       // a join of this process needed 16-byte intermediates: launch those kernels from now on
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
@@ -100,7 +104,7 @@ struct Ctx {
     hipEvent_t  ev[ST_N + 1] = {};
     hipEvent_t  ev_x[4] = {};
     Buf partR, partS, tmpR, tmpS, cntR, cntS, chunk, histpsum, passhp, units, bunits, ldsb, meta, summary,
-        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, lr_tmp, lr_words, lr_status, stripR, stripS, slice_tot, sbase;
+        ucount, ubase, uflag, tab32, tab64, stash_cnt, stash_row, status, dbg, bsum, digR, digS, ovf, ovf_base, runR, runS, walk, xrows, lr_tmp, lr_words, lr_status, stripR, stripS, slice_tot, sbase;
     Buf inR, inS, out, fcol_sel, fmask, ftile, fbase, fout;
     void *pin = nullptr;            // small pinned block for read-backs
     void *pin_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // D2H staging of result pairs (16 MiB each)
@@ -139,6 +143,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
         if ((e = getenv("RHJ_NO_LOWRADIX"))) g.no_lowradix = atoi(e);
         if ((e = getenv("RHJ_NO_SPEC"))) g.no_spec = atoi(e);
+        if ((e = getenv("RHJ_NO_EXACT"))) g.no_exact = atoi(e);
         if ((e = getenv("RHJ_LO_BITS"))) g.lo_override = atoi(e);
         if ((e = getenv("RHJ_NO_COUNT_IN_PASS1"))) g.no_count_in_pass1 = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
@@ -199,6 +204,7 @@ int ctx_init()
         for (const void *k : fused)
             HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
         HIP_TRY(hipFuncSetAttribute((const void *)k_join_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_join_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET - FJ_LDS_EXTRA)));
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_small_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(PT_MAX_BITS)));
     HIP_TRY(hipFuncSetAttribute((const void *)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << MAX_BITS)));
@@ -572,7 +578,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.spec = 0; fa.pad = 0;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.spec = 0; fa.xrows = nullptr;
         fa.unit_bound = unit_bound;
         fa.host_summary = (uint64_t *)g.pin;
         fa.dbg = nullptr;
@@ -678,7 +684,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         fa.status = (uint64_t *)g.status.p + 8;               // words 0..7 hold the ticket
         fa.ticket = (uint32_t *)g.status.p;
         fa.nR = nR;
-        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.spec = 0; fa.pad = 0;
+        fa.allow_resident = !g.no_resident; fa.radix_bits = (uint32_t)bits; fa.lr_mode = 0; fa.spec = 0; fa.xrows = nullptr;
         fa.unit_bound = unit_bound;
         fa.host_summary = nullptr;
         fa.dbg = nullptr;
@@ -712,14 +718,30 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             // The foreign-key speculation (k_join_spec): the bigger relation's tuples have one match each?  Then nothing is
             // stashed for the units that relation probes and nothing is chained.  Tried while it keeps holding; a failed try
             // costs the time to the first unit that notices (tens of microseconds), so after failures only every 16th join tries.
+            // (A buffer below the relation's size is no obstacle: pairs beyond it are dropped as on every path and the caller hears
+            // the count.  A rank's share of a sharded join — rhj_join_device_range — has a buffer for its share and buckets of the
+            // whole join's size: the per-bucket rule is the same.)
             bool try_spec = attempt == 0 && maybe_narrow && out != nullptr && g.no_spec <= 0 && !g.ablate &&
-                            out_capacity >= (nS >= nR ? nS : nR) &&
                             (nS >= nR ? nS : nR) / bins >= 4096;     // (units of 2.4 K tuples: 10M x 10M at 12 bits lost 7 % to its per-unit extras)
             if (try_spec && g.spec_score <= 0 && g.no_spec >= 0 && ++g.spec_skipped < 16) try_spec = false;   // (RHJ_NO_SPEC=-1: always try — to time a failing one)
             fa.spec = try_spec ? (nS >= nR ? 1u : 2u) : 0u;
+            // k_join_exact (rhj_join_exact.hip.h) runs the speculation over an index that needs no verifying gather: build sides
+            // the gather kernels would take (beyond the LDS-resident ones), enough radix bits for its slots to make the 40 stored
+            // hash bits exact.  It hands over (ticket[4], reason in ticket[5]) what it does not take; a join it handed back for
+            // its INPUT (row ids that do not increase, a bucket beyond its index) makes the next eligible joins skip it.
+            bool try_exact = try_spec && g.no_exact <= 0 && !(nmin / bins <= 7000 && !g.no_resident) && bits >= 10 &&
+                             nmin / bins <= XJ_MAX_BUILD;
+            if (try_exact && g.exact_score <= 0 && g.no_exact >= 0 && ++g.exact_skipped < 16) try_exact = false;
+            if (try_exact) {
+                if (ensure(g.xrows, (size_t)g.cus * XJ_SCRATCH * 4)) return -1;
+                fa.xrows = (uint32_t *)g.xrows.p;
+                g.exact_skipped = 0;
+            }
             if (try_spec) {
                 g.spec_skipped = 0;
-                if (nmin / bins <= 7000 && !g.no_resident)
+                if (try_exact)
+                    RHJ_LAUNCH(k_join_exact, dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
+                else if (nmin / bins <= 7000 && !g.no_resident)
                     RHJ_LAUNCH((k_join_spec<true>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
                 else
                     RHJ_LAUNCH((k_join_spec<false>), dim3(fgrid), dim3(FJ_BLOCK), fused_lds, g.stream, fa, fused_lds);
@@ -744,11 +766,20 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             HIP_TRY(hipStreamSynchronize(g.stream));
             plan = *hs;
             g.last_spec = 0;
+            g.last_exact = 0;
             if (try_spec) {
                 const bool held = spec_words[4] == 0;
+                const bool not_taken = try_exact && !held && spec_words[5] == 2;     // k_join_exact's input, not the hypothesis
                 g.last_spec = held ? 1 : 2;
-                g.spec_score = held ? (g.spec_score < 4 ? g.spec_score + 1 : 4) : g.spec_score - 2;
-                if (g.spec_score < -2) g.spec_score = -2;
+                if (try_exact) {
+                    g.last_exact = held ? 1 : 2;
+                    g.exact_score = not_taken ? g.exact_score - 2 : (g.exact_score < 4 ? g.exact_score + 1 : 4);
+                    if (g.exact_score < -2) g.exact_score = -2;
+                }
+                if (!not_taken) {
+                    g.spec_score = held ? (g.spec_score < 4 ? g.spec_score + 1 : 4) : g.spec_score - 2;
+                    if (g.spec_score < -2) g.spec_score = -2;
+                }
             }
             if (plan.row_id_overflow) { *overflow = true; return 0; }     // (also: wide row ids met the 12-byte kernels alone)
             if (plan.fused_ok && plan.matches == FJ_NO_TOTAL && !g.ablate) { fprintf(stderr, "rhj: fused join left no match total (chained scan incomplete)\n"); return -1; }
@@ -918,7 +949,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     FusedArgs fa;
     fa.stash_cnt = (uint8_t *)g.stash_cnt.p; fa.stash_row = (uint64_t *)g.stash_row.p;
     fa.status = (uint64_t *)g.status.p + 8; fa.ticket = (uint32_t *)g.status.p;
-    fa.nR = nR; fa.allow_resident = 0; fa.radix_bits = (uint32_t)T; fa.lr_mode = 1; fa.spec = 0; fa.pad = 0;
+    fa.nR = nR; fa.allow_resident = 0; fa.radix_bits = (uint32_t)T; fa.lr_mode = 1; fa.spec = 0; fa.xrows = nullptr;
     fa.unit_bound = unit_bound; fa.host_summary = nullptr; fa.dbg = nullptr;
     fa.ovf = (uint64_t *)g.ovf.p; fa.ovf_base = (uint32_t *)g.ovf_base.p; fa.walk = (FjWalkItem *)g.walk.p;
     const uint32_t fused_lds = LDS_BUDGET - FJ_LDS_EXTRA;
@@ -1169,6 +1200,8 @@ void rhj_set_small(int on) { g.no_small = !on; }
 void rhj_set_lowradix(int on) { g.no_lowradix = !on; }
 void rhj_set_spec(int on) { g.no_spec = !on; g.spec_score = 2; g.spec_skipped = 0; }
 int rhj_last_spec(void) { return g.last_spec; }
+void rhj_set_exact(int on) { g.no_exact = !on; g.exact_score = 2; g.exact_skipped = 0; }
+int rhj_last_exact(void) { return g.last_exact; }
 void rhj_set_count_in_pass1(int on) { g.no_count_in_pass1 = !on; }
 void rhj_set_order(int any) { g.order_any = any != 0; }
 int rhj_auto_radix_bits(uint64_t nR, uint64_t nS) { return auto_radix_bits(nR, nS); }

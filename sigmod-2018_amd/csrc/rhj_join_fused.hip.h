@@ -52,13 +52,14 @@ struct FusedArgs {
     uint64_t *status;         // [units] (flag << 62) | value ; flag 1 = unit total, 2 = inclusive prefix
     uint32_t *ticket;         // word 0: next unit; word 1: workgroups that are through (the last one out leaves the match total);
                               // word 2: entries of the walk list; word 3: k_join_walk's own ticket; word 4: the foreign-key
-                              // speculation failed (k_join_spec); words 6..7 (one u64): the totals it predicted, summed
+                              // speculation failed (k_join_spec, k_join_exact); word 5: why k_join_exact gave up (1 a check of the
+                              // speculation failed, 2 an input it does not take); words 6..7 (one u64): the totals it predicted, summed
     uint64_t  nR;
     uint32_t  allow_resident;
     uint32_t  radix_bits;     // the join's radix width (the bits every key of a bucket shares)
     uint32_t  lr_mode;        // low-radix path (rhj_lowradix.hip.h): a tuple with several matches leaves the place of its pairs in its stash row
     uint32_t  spec;           // foreign-key speculation (k_join_spec, below): 0 none, 1 every S tuple has exactly one match, 2 every R tuple
-    uint64_t  pad;
+    uint32_t *xrows;          // k_join_exact (rhj_join_exact.hip.h): [grid][XJ_SCRATCH] a unit's build row ids in entry order
     uint64_t  unit_bound;     // status words there are
     uint64_t *host_summary;   // pinned host block that receives the plan summary (with the match total) at the end, or null
     uint64_t *dbg;            // diagnostic builds only: [units][8] phase stamps (100 MHz), else null
@@ -479,7 +480,11 @@ __device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> 
 #pragma unroll
         for (int k = 0; k < FJ_V; ++k) {
             g[k] = make_uint4(0, 0, 0, 0);
+#ifdef FJ_FLOOR          // timing experiment only (wrong results): every tag hit is taken for a match, its position for the row id
+            if (pos[k] != 0xffffffffu) g[k] = make_uint4(q[k].x, q[k].y, pos[k], 0u);
+#else
             if (pos[k] != 0xffffffffu) g[k] = RES ? ltup[pos[k]] : G.load(pos[k]);
+#endif
         }
         bool ex[FJ_V];
 #pragma unroll
@@ -965,7 +970,11 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     const bool flip = bucket_flip(a, b, cR, cS);                       // S is streamed (r_s == 1)
     const uint64_t ppos = (flip ? a.psumS[b] : a.psumR[b]) + un.off;   // position in the probe relation
     // SPEC: the probe side is the relation of the hypothesis (fkp); the unit's predicted first pair and pair count
+#ifdef FJ_FLOOR              // timing experiment only: EVERY unit writes its pairs from the probe loop (no stash, no emit pass, no check)
+    const bool fkp = SPEC;
+#else
     const bool fkp = SPEC && (flip == (f.spec == 1u));
+#endif
     const uint64_t spec_base = SPEC ? (f.spec == 1u ? a.psumS[b] : a.psumR[b]) + (fkp ? un.off : 0u) : 0u;
     const uint64_t spec_total = SPEC ? (fkp ? (uint64_t)un.count : (f.spec == 1u ? cS : cR)) : 0u;
     bool spec_bad = SPEC && !fkp && (un.off != 0 || un.count != (flip ? cS : cR));   // (a split bucket's later units cannot know their base)
@@ -1043,7 +1052,9 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             for (int k = 0; k < FJ_V; ++k) {
                 const uint32_t i = t0 + k * WAVE + lane;
                 if (i < un.count) {
+#ifndef FJ_FLOOR
                     spec_bad = spec_bad || c[k] != 1u;
+#endif
                     const uint64_t at = spec_base + i;
                     if (at < a.out_capacity) out[at] = make_pair(flip, q[k].z, N32 ? 0u : q[k].w, flo[k], fhi[k]);
                 }
@@ -1208,6 +1219,9 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_spec(FusedArgs f, uint32_t ld
         const uint32_t last = (1u << f.radix_bits) - 1u;
         const uint64_t n_fk = f.spec == 1u ? f.j.psumS[last] + f.j.histS[last] : f.j.psumR[last] + f.j.histR[last];
         bool failed = __hip_atomic_load(f.ticket + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || predicted != n_fk;
+#ifdef FJ_FLOOR
+        failed = false;
+#endif
         if (failed) {                                 // the ordinary kernel behind this one starts over
             __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(f.ticket + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

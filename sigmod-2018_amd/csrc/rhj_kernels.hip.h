@@ -44,6 +44,7 @@
 #include "rhj_partition.hip.h"
 #include "rhj_join_tiled.hip.h"
 #include "rhj_join_fused.hip.h"
+#include "rhj_join_exact.hip.h"
 #include "rhj_lowradix.hip.h"
 #include "rhj_small.hip.h"
 #include "rhj_filter.hip.h"

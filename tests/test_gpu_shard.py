@@ -97,6 +97,56 @@ def test_sharded_join_on_the_device_under_nccl(rhj, shard, oracle, nccl_world, k
                     assert ((b >= lo) & (b < hi)).all()
 
 
+@pytest.mark.parametrize("bits,n,spec", [(8, 5_000_000, 0), (12, 5_000_000, 0), (10, 5_000_000, 1), (10, 8_000_000, 1)])
+def test_ranged_join_at_the_sizes_a_sharded_run_has(rhj, shard, oracle, bits, n, spec):
+    """rhj_join_device_range where a 100 M-tuple multi-GPU run takes it: more than 1024 tiles a relation (the chunked scan of
+    the one-pass partition, k_local_part<RANGED> over strips of several tiles with the counts taken in pass 1, k_group_scan /
+    k_bucket_psum over thinned tiles), the fused join and the foreign-key speculation (k_join_spec at 4.9 K tuples a bucket,
+    k_join_exact at 7.8 K) on a ranged partition.  Every range of a three-way split, equal-width and histogram-balanced:
+    the concatenation is the plain call's result bit for bit, which is the oracle's.
+    Regression guard for the fault of profiles/README.md r03i (round 3): thinned tiles (kept < count) in k_scatter_lds<RANGED>
+    and S's offsets behind R's KEPT tuples in k_small_scan_plan — the 8-bit case walks both at 1221 tiles a relation."""
+    ops = shard.RhjOps(rhj)
+    R = oracle.generate(n, 0, 0, 0.0, 71)
+    S = oracle.generate(n, 1, n, 0.0, 72)
+    dR, dS = rhj.to_device(R), rhj.to_device(S)
+    want = oracle.join(R, S, bits)
+    rhj.set_bits(bits)
+    rhj.lib.rhj_set_spec(1)
+    rhj.lib.rhj_set_exact(1)
+    plain, m = rhj.join_device(dR, dS, capacity=n)
+    assert m == len(want) and np.array_equal(rhj.pairs_to_numpy(plain)[:m], want)
+    assert rhj.lib.rhj_last_spec() == spec
+    del plain
+    mask = np.uint64((1 << bits) - 1)
+    hr = np.bincount((R["value"] & mask).astype(np.int64), minlength=1 << bits)
+    hs = np.bincount((S["value"] & mask).astype(np.int64), minlength=1 << bits)
+    for ranges in (shard.equal_ranges(bits, 3), shard.bucket_ranges(hr, hs, 3)):
+        at = 0
+        for rng in ranges:
+            part = rhj.pairs_to_numpy(ops.join(dR, dS, bits, rng))
+            assert rhj.lib.rhj_last_spec() == spec, (bits, rng)       # the speculation is tried on a rank's share as on the whole join
+            assert np.array_equal(part, want[at:at + len(part)]), (bits, rng)
+            at += len(part)
+        assert at == len(want)
+    if spec:
+        # one S tuple without a partner, in the middle range: that rank's speculation fails (the ordinary kernel takes over in the
+        # same call), the other ranks' holds
+        S2 = S.copy()
+        victim = int(np.nonzero((S2["value"] & mask) == np.uint64((1 << bits) // 2))[0][0])
+        S2["value"][victim] = (S2["value"][victim] & mask) | np.uint64(1 << 62)
+        want2 = oracle.join(R, S2, bits)
+        dS2 = rhj.to_device(S2)
+        at, went = 0, []
+        for rng in shard.equal_ranges(bits, 3):
+            rhj.lib.rhj_set_spec(1)
+            part = rhj.pairs_to_numpy(ops.join(dR, dS2, bits, rng))
+            went.append(rhj.lib.rhj_last_spec())
+            assert np.array_equal(part, want2[at:at + len(part)]), (bits, rng)
+            at += len(part)
+        assert at == len(want2) and went == [1, 2, 1]
+
+
 def test_allgatherv_and_independent_joins_on_device_tensors(rhj, shard, oracle, nccl_world):
     import torch
     ops = shard.RhjOps(rhj)
