@@ -134,7 +134,8 @@ def load_library(path=None):
     L.rhj_set_count_in_pass1.argtypes = [C.c_int]
     L.rhj_set_spec.argtypes = [C.c_int]
     L.rhj_last_spec.restype = C.c_int
-    L.rhj_last_exact.restype = C.c_int
+    if hasattr(L, "rhj_last_exact"):              # (A/B runs load earlier builds through this module too)
+        L.rhj_last_exact.restype = C.c_int
     L.rhj_set_order.argtypes = [C.c_int]
     L.rhj_get_order.restype = C.c_int
     L.rhj_auto_radix_bits.argtypes = [C.c_uint64, C.c_uint64]

@@ -89,7 +89,7 @@ struct Ctx {
     int         spec_score = 2;      // > 0: try it (a speculation that holds adds 1, up to 4; one that fails takes 2 off)
     int         spec_skipped = 0;    // joins not speculated on since the score went to zero: every 16th tries again
     int         last_spec = 0;       // the last join: 0 not tried, 1 held, 2 failed (rhj_last_spec)
-    int         no_exact = 0;        // 1: never launch k_join_exact (env RHJ_NO_EXACT; rhj_set_exact(0))
+    int         no_exact = 1;        // 1: never launch k_join_exact (the default: it measured slower than the gather kernels, profiles/README.md r04a; env RHJ_EXACT=1 / rhj_set_exact(1) turn it on)
     int         exact_score = 2;     // > 0: launch it where it applies (a join it did adds 1, up to 4; one it handed back for its input takes 2 off)
     int         exact_skipped = 0;   // eligible joins not given to it since the score went to zero: every 16th tries again
     int         last_exact = 0;      // the last join: 0 not launched, 1 k_join_exact did the join, 2 it handed over (rhj_last_exact)
@@ -143,7 +143,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NO_SMALL"))) g.no_small = atoi(e);
         if ((e = getenv("RHJ_NO_LOWRADIX"))) g.no_lowradix = atoi(e);
         if ((e = getenv("RHJ_NO_SPEC"))) g.no_spec = atoi(e);
-        if ((e = getenv("RHJ_NO_EXACT"))) g.no_exact = atoi(e);
+        if ((e = getenv("RHJ_EXACT"))) g.no_exact = !atoi(e);
         if ((e = getenv("RHJ_LO_BITS"))) g.lo_override = atoi(e);
         if ((e = getenv("RHJ_NO_COUNT_IN_PASS1"))) g.no_count_in_pass1 = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;

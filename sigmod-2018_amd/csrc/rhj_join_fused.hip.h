@@ -34,7 +34,7 @@ constexpr int FJ_WAVES = FJ_BLOCK / WAVE;
 constexpr int FJ_V = 4;
 constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
 constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
-constexpr uint32_t FJ_LDS_EXTRA = 1024;         // bytes of LDS behind the table
+constexpr uint32_t FJ_LDS_EXTRA = 2048;         // bytes of LDS behind the table (static: the words below, the speculative kernel's group prefixes)
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
 constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
 #ifndef FJ_WIN
@@ -455,16 +455,17 @@ struct FjGather {
 // stored; more than 16 matches of one tuple, a full overflow buffer or patch list send the unit to k_join_walk.
 struct FjOvf {
     uint64_t *buf;        // this unit's overflow entries
-    uint32_t *table;      // this unit's [group][16] run starts
+    uint32_t *table;      // this unit's [group][16] run starts (null: the wave keeps them itself, FjOvf::runs)
     uint32_t *counter;    // LDS bump counter
     uint32_t  gid;        // group of this wave in this batch
+    uint32_t  runs;       // table == null: lane r holds the start of the run of match round r (what the table's row would hold)
 };
 
 template <bool RES, bool OVF, bool N32, class IX>
 __device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> &G, const uint4 *ltup,
                                                const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V], uint32_t (&c)[FJ_V],
                                                uint32_t (&flo)[FJ_V], uint32_t (&fhi)[FJ_V], bool (&fp)[FJ_V],
-                                               uint32_t (&bm)[FJ_V], const FjOvf &O)
+                                               uint32_t (&bm)[FJ_V], FjOvf &O)
 {
     uint32_t sn[FJ_V], tm[FJ_V];
 #pragma unroll
@@ -511,9 +512,10 @@ __device__ __forceinline__ void fj_count_batch(const IX &X, const FjGather<N32> 
                 uint32_t base = 0;
                 if (lane == 0) {
                     base = atomicAdd(O.counter, tot);
-                    if (round <= FJ_OVF_J) O.table[O.gid * 16u + round] = base;
+                    if (round <= FJ_OVF_J && O.table) O.table[O.gid * 16u + round] = base;
                 }
                 base = __builtin_amdgcn_readfirstlane(base);
+                if (!O.table && lane == round) O.runs = base;
                 uint32_t pre = base;
 #pragma unroll
                 for (int k = 0; k < FJ_V; ++k) {
@@ -656,6 +658,35 @@ __device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t
     return excl;
 }
 
+// Exclusive prefix of a unit's 256-tuple group g over the groups in front of it, for the waves of ONE workgroup that take the
+// groups from a counter (so the groups below g are done or in the hands of waves that never wait for g): the chained scan of
+// fj_lookback in LDS.  gp[g] = (flag << 30) | value, flag 1 = the group's total, 2 = its inclusive prefix; cleared per unit.
+__device__ __forceinline__ uint32_t fj_group_lookback(uint32_t *gp, uint32_t g, uint32_t total, uint32_t lane)
+{
+    if (lane == 0) __hip_atomic_store(&gp[g], ((g == 0 ? 2u : 1u) << 30) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (g == 0) return 0;
+    uint32_t excl = 0;
+    int32_t j = (int32_t)g - 1;
+    for (;;) {
+        const int32_t idx = j - (int32_t)lane;
+        uint32_t v = 2u << 30;                        // virtual "prefix 0" in front of group 0
+        if (idx >= 0) {
+            do {
+                v = __hip_atomic_load(&gp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((v >> 30) == 0) __builtin_amdgcn_s_sleep(1);
+            } while ((v >> 30) == 0);
+        }
+        const uint64_t full = __ballot((v >> 30) == 2u);
+        const int stop = full ? __ffsll((unsigned long long)full) - 1 : 64;   // nearest inclusive prefix
+        const uint32_t part = wave_incl_scan_u32(lane <= (uint32_t)stop ? (v & 0x3fffffffu) : 0u);
+        excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+        if (full) break;
+        j -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&gp[g], (2u << 30) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return excl;
+}
+
 // The first-match stash is 8 bytes per probe tuple: the build row id — or, when the partition found every row
 // id below 2^32 (N32: summary->wide_row_ids == 0; pass 1 checks every tuple and the host runs again wide
 // otherwise), the low words of the build AND the probe row id, so that the deferred emit pass does not read
@@ -663,6 +694,83 @@ __device__ __forceinline__ uint64_t fj_lookback(unsigned long long *st, uint32_t
 template <bool N32> __device__ __forceinline__ void fj_stash_put(uint2 *srow, uint32_t i, uint32_t lo, uint32_t hi, uint32_t probe_lo)
 {
     srow[i] = N32 ? make_uint2(lo, probe_lo) : make_uint2(lo, hi);
+}
+
+// The pairs of one 256-tuple group (one wave) from registers: c = matches per tuple, B = the rounds they were found in (bit r:
+// round r), first = the first match's build row id, prow = the probe tuple's row id; tbl_v: lane j = start of the overflow run
+// of round j (lane 0 unused); wbase = the group's first output position.  Called by fj_emit_stream with what phase 1 stashed,
+// and by the speculative kernel straight from phase 1 (fj_body, SPEC: the other relation probes).
+template <bool DUP, bool N32>
+__device__ __forceinline__ void fj_emit_group(bool flip, const uint32_t (&c)[FJ_V], const uint32_t (&B)[FJ_V],
+                                              const uint2 (&first)[FJ_V], const uint2 (&prow)[FJ_V], uint32_t tbl_v, uint64_t wbase,
+                                              const uint64_t *ovf, uint4 *out, uint64_t cap, uint2 *lr_row)
+{
+    constexpr int V = FJ_V;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt = lanemask_lt();
+    uint32_t off[V], wrun = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        if (DUP) {
+            uint32_t tot;
+            off[k] = wrun + wave_excl_scan_u32(c[k], &tot);
+            wrun += tot;
+        } else {
+            const uint64_t m = __ballot(c[k] != 0);
+            off[k] = wrun + (uint32_t)__popcll(m & lt);
+            wrun += (uint32_t)__popcll(m);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint64_t at = wbase + off[k];
+        if (c[k] != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
+        if (DUP && N32 && lr_row && c[k] >= 2u)        // low-radix path: k_lr_emit copies this tuple's pairs from here
+            lr_row[k * WAVE + lane] = make_uint2((uint32_t)at, prow[k].x);
+    }
+    if (DUP) {
+        // second and later matches: ordinal j of the group's tuples sits in one run of the overflow
+        // stash, in (k, lane) order (fj_count_batch).  Four ordinals per step, loads before stores.
+        for (uint32_t j0 = 1;; j0 += 4) {
+            uint2 r[4][V];
+            bool any = false;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint32_t j = j0 + jj;
+                uint64_t mk[V];
+                uint32_t tot = 0;
+                bool later = false;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    // round j left an overflow entry of this tuple: a match found there that is not the tuple's first
+                    mk[k] = __ballot(((B[k] >> j) & 1u) != 0 && (B[k] & ((1u << j) - 1u)) != 0);
+                    tot += (uint32_t)__popcll(mk[k]);
+                    later = later || (B[k] >> j) > 1u;
+                }
+                any = any || tot != 0 || __ballot(later) != 0;
+                uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, (int)(j & 15u));
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
+                    r[jj][k] = make_uint2(0, 0);
+                    if ((mk[k] >> lane) & 1ull) r[jj][k] = reinterpret_cast<const uint2 *>(ovf)[min(slot, FJ_OVF_CAP - 1u)];   // (a run beyond the buffer: the unit is redone)
+                    pre += (uint32_t)__popcll(mk[k]);
+                }
+            }
+            if (!any) break;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint32_t j = j0 + jj;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const uint32_t before = B[k] & ((1u << j) - 1u);       // the matches of earlier rounds come first
+                    const uint64_t at = wbase + off[k] + (uint32_t)__popc(before);
+                    if (((B[k] >> j) & 1u) != 0 && before != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, r[jj][k].x, r[jj][k].y);
+                }
+            }
+            if (j0 + 4 > FJ_OVF_J) break;
+        }
+    }
 }
 
 // Deferred emit pass of a gather-path unit: pure streaming of the probe row ids, the stash and (DUP)
@@ -685,7 +793,6 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
     const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const uint64_t cap = a.out_capacity;
-    const uint64_t lt = lanemask_lt();
     const uint32_t ngroups = (un.count + 255u) >> 8;
 
     // group totals (phase 1 left them in column 0 of the table) -> exclusive starts, once per unit;
@@ -739,70 +846,9 @@ __device__ __forceinline__ void fj_emit_stream(const FusedArgs &f, uint32_t u, u
         // the group's table row: lane 0 its start in the unit's output, lane j the run start of ordinal j
         uint32_t tbl_v = 0;
         if (lane < 16) tbl_v = __hip_atomic_load(&table[g * 16u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint32_t off[V], wrun = 0;
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            if (DUP) {
-                uint32_t tot;
-                off[k] = wrun + wave_excl_scan_u32(c[k], &tot);
-                wrun += tot;
-            } else {
-                const uint64_t m = __ballot(c[k] != 0);
-                off[k] = wrun + (uint32_t)__popcll(m & lt);
-                wrun += (uint32_t)__popcll(m);
-            }
-        }
         const uint64_t wbase = base + (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, 0);
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const uint64_t at = wbase + off[k];
-            if (c[k] != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, first[k].x, first[k].y);
-            if (DUP && N32 && f.lr_mode && c[k] >= 2u)     // low-radix path: k_lr_emit copies this tuple's pairs from here
-                const_cast<uint2 *>(srow)[g * 256u + k * WAVE + lane] = make_uint2((uint32_t)at, prow[k].x);
-        }
-        if (DUP) {
-            // second and later matches: ordinal j of the group's tuples sits in one run of the overflow
-            // stash, in (k, lane) order (fj_count_batch).  Four ordinals per step, loads before stores.
-            for (uint32_t j0 = 1;; j0 += 4) {
-                uint2 r[4][V];
-                bool any = false;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const uint32_t j = j0 + jj;
-                    uint64_t mk[V];
-                    uint32_t tot = 0;
-                    bool later = false;
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        // round j left an overflow entry of this tuple: a match found there that is not the tuple's first
-                        mk[k] = __ballot(((B[k] >> j) & 1u) != 0 && (B[k] & ((1u << j) - 1u)) != 0);
-                        tot += (uint32_t)__popcll(mk[k]);
-                        later = later || (B[k] >> j) > 1u;
-                    }
-                    any = any || tot != 0 || __ballot(later) != 0;
-                    uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)tbl_v, (int)(j & 15u));
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        const uint32_t slot = pre + (uint32_t)__popcll(mk[k] & lt);
-                        r[jj][k] = make_uint2(0, 0);
-                        if ((mk[k] >> lane) & 1ull) r[jj][k] = reinterpret_cast<const uint2 *>(ovf)[slot];
-                        pre += (uint32_t)__popcll(mk[k]);
-                    }
-                }
-                if (!any) break;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const uint32_t j = j0 + jj;
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        const uint32_t before = B[k] & ((1u << j) - 1u);       // the matches of earlier rounds come first
-                        const uint64_t at = wbase + off[k] + (uint32_t)__popc(before);
-                        if (((B[k] >> j) & 1u) != 0 && before != 0 && at < cap) out[at] = make_pair(flip, prow[k].x, prow[k].y, r[jj][k].x, r[jj][k].y);
-                    }
-                }
-                if (j0 + 4 > FJ_OVF_J) break;
-            }
-        }
+        fj_emit_group<DUP, N32>(flip, c, B, first, prow, tbl_v, wbase, ovf, out, cap,
+                                f.lr_mode ? const_cast<uint2 *>(srow) + g * 256u : nullptr);
     }
 }
 
@@ -905,6 +951,117 @@ __device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, con
     }
 }
 
+// SPEC, the other relation probes a gathered build side (fj_body): one 256-tuple group from its keys to its pairs, by one wave.
+// Round 0 takes every tuple's first candidate, four gathers a lane as in fj_count_batch.  What is left — the second and later
+// candidates of the tuples that have them: a quarter of the tuples of a foreign-key join's unique side — is walked LANE BY LANE:
+// every step each lane takes the next candidate of the first of its four tuples that has one, so a step is ONE gather with most
+// lanes busy (a round per match ordinal was four gathers with a quarter, a twelfth, a fiftieth of the lanes: the vector memory
+// instructions a group issues, not their lanes, set this phase's pace — 70 a group with the overflow runs and the four-ordinal
+// emit loop, profiles/README.md r04b).  A second or later match leaves a 16-byte record {build row id, probe row id, tuple,
+// ordinal} in the wave's own piece of the overflow buffer (always the same 4 KB: L1/L2-resident); the matches of a tuple are
+// found in slot order = descending build position (rhjoin.c:219-250), so the ordinal is the number found before.  Then the
+// group's total goes into the chained scan of the unit's groups (fj_group_lookback), the first matches leave from the
+// registers and the records are read back 64 at a time, each pair to its tuple's offset + ordinal.  Returns the lane's matches.
+constexpr uint32_t FJ_REC_CAP = 256;                  // records (second and later matches) of one group; more: the speculation is off
+template <bool N32, class IX>
+__device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<N32> &G, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
+                                                    bool flip, uint32_t grp, uint32_t *gpre, uint64_t spec_base, uint4 *rec,
+                                                    uint4 *out, uint64_t cap, bool &cannot)
+{
+    constexpr int V = FJ_V;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt = lanemask_lt();
+    uint32_t sn[V], tm[V], c[V], first[V];
+    // (The lane-by-lane loop below picks one of the lane's four tuples by a run-time index.  hipcc turns a select between
+    // loads of the caller's array into a load through a selected POINTER — and the array into 64 bytes of scratch per lane;
+    // values that come out of an (empty) asm statement are not loads any more.)
+    uint32_t qx[V], qy[V], qz[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        qx[k] = q[k].x; qy[k] = q[k].y; qz[k] = q[k].z;
+        asm volatile("" : "+v"(qx[k]), "+v"(qy[k]), "+v"(qz[k]));
+    }
+    {
+        uint32_t pos[V];
+        uint4 g[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            fj_lookup(X, ((uint64_t)q[k].y << 32) | q[k].x, okk[k], sn[k], tm[k]);
+            pos[k] = 0xffffffffu;
+            const uint32_t m = tm[k] & 0xffu;
+            if (m != 0) { pos[k] = X.ent[(sn[k] & 0xffffu) + (uint32_t)__builtin_ctz(m)] & 0xffffu; tm[k] &= tm[k] - 1u; }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) g[k] = pos[k] != 0xffffffffu ? G.load(pos[k]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const bool eq = pos[k] != 0xffffffffu && g[k].x == q[k].x && g[k].y == q[k].y;
+            first[k] = eq ? g[k].z : 0u;
+            c[k] = eq ? 1u : 0u;
+        }
+    }
+    uint32_t ne = 0;                                   // records of this group so far (wave-uniform)
+    for (;;) {
+        uint32_t ks = V;                               // the first of the lane's tuples with a candidate left
+#pragma unroll
+        for (int k = V - 1; k >= 0; --k)
+            if ((tm[k] & 0xffu) != 0 || (sn[k] >> 16) > (uint32_t)FJ_WIN) ks = (uint32_t)k;
+        if (__ballot(ks < (uint32_t)V) == 0) break;
+        uint32_t s_ = sn[0], t_ = tm[0], kx = qx[0], ky = qy[0], pr = qz[0], cc = c[0];
+#pragma unroll
+        for (int k = 1; k < V; ++k)
+            if (ks == (uint32_t)k) { s_ = sn[k]; t_ = tm[k]; kx = qx[k]; ky = qy[k]; pr = qz[k]; cc = c[k]; }
+        uint32_t p = 0xffffffffu;
+        if (ks < (uint32_t)V) {
+            if ((t_ & 0xffu) == 0) {                   // the window is used up and the slot goes on
+                s_ += (uint32_t)FJ_WIN - ((uint32_t)FJ_WIN << 16);
+                t_ |= fj_window(X, s_ & 0xffffu, s_ >> 16, t_ & 0xffff0000u);
+            }
+            const uint32_t m = t_ & 0xffu;
+            if (m != 0) { p = X.ent[(s_ & 0xffffu) + (uint32_t)__builtin_ctz(m)] & 0xffffu; t_ &= t_ - 1u; }
+        }
+        const uint4 g = p != 0xffffffffu ? G.load(p) : make_uint4(0, 0, 0, 0);
+        const bool eq = p != 0xffffffffu && g.x == kx && g.y == ky;
+        const bool isrec = eq && cc != 0;
+        const uint64_t mk = __ballot(isrec);
+        const uint32_t slot = ne + (uint32_t)__popcll(mk & lt);
+        if (isrec && slot < FJ_REC_CAP) rec[slot] = make_uint4(g.z, pr, (ks * WAVE + lane) | (cc << 8), 0u);
+        ne += (uint32_t)__popcll(mk);
+        cannot = cannot || (eq && cc >= 255u);         // (the ordinal has eight bits)
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (ks == (uint32_t)k) { sn[k] = s_; tm[k] = t_; if (eq) { if (cc == 0) first[k] = g.z; c[k] = cc + 1u; } }
+    }
+    cannot = cannot || ne > FJ_REC_CAP;
+    uint32_t off[V], wrun = 0, cs = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        uint32_t tot;
+        off[k] = wrun + wave_excl_scan_u32(c[k], &tot);
+        wrun += tot;
+        cs += c[k];
+    }
+    const uint64_t wbase = spec_base + fj_group_lookback(gpre, grp, wrun, lane);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint64_t at = wbase + off[k];
+        if (c[k] != 0 && at < cap) out[at] = make_pair(flip, q[k].z, 0u, first[k], 0u);
+    }
+    const uint32_t nrec = min(ne, FJ_REC_CAP);
+    for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
+        const uint32_t e = e0 + lane;
+        const uint4 r = e < nrec ? rec[e] : make_uint4(0, 0, 0, 0);
+        const int src = (int)(r.z & 63u);
+        const uint32_t kk = (r.z >> 6) & 3u;
+        uint32_t o = __shfl(off[0], src, 64);
+#pragma unroll
+        for (int k = 1; k < V; ++k) { const uint32_t ok_ = __shfl(off[k], src, 64); if (kk == (uint32_t)k) o = ok_; }
+        const uint64_t at = wbase + o + (r.z >> 8);
+        if (e < nrec && at < cap) out[at] = make_pair(flip, r.y, 0u, r.x, 0u);
+    }
+    return cs;
+}
+
 // MAYRES = false compiles the gather path only (the host picks it when the average bucket
 // cannot fit LDS anyway); MAYRES = true decides per unit.
 // A workgroup takes units through the ticket until none is left.  The emit pass of a unit that does
@@ -941,6 +1098,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     __shared__ uint32_t sh_pick;
     __shared__ uint64_t sh_base;
     __shared__ uint32_t wsum[FJ_WAVES];
+    __shared__ uint32_t gpre[SPEC ? FJ_GROUPS : 1];     // SPEC, the other relation probes: the groups' totals / prefixes (fj_group_lookback)
     const JoinArgs &a = f.j;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned long long *st = (unsigned long long *)f.status;
@@ -961,6 +1119,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         // (SPEC: a failed check anywhere ends the kernel — one thread reads the word, so the whole workgroup agrees)
         if (SPEC && __hip_atomic_load(f.ticket + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) sh_u = 0xffffffffu;
     }
+    if (SPEC && threadIdx.x < FJ_GROUPS) gpre[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t u = sh_u;
     if (u >= a.summary->units || !a.summary->fused_ok) break;         // grid is an upper bound; tiled path takes over
@@ -1042,6 +1201,15 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         }
         O.gid = grp;
         uint32_t run[FJ_V], bm[FJ_V];
+        if (SPEC && !fkp && !RES) {
+            // SPEC, the OTHER relation probes a gathered build side: the unit's first pair is known (the hypothesis' relation's
+            // psum), so all a group needs is the match total of the groups in front of it — a chained scan among the waves of
+            // this workgroup, in LDS — and its pairs go out from here (fj_group_direct): no stash, no emit pass.
+            mine += fj_group_direct<N32>(X, G, q, okk, flip, grp, gpre, spec_base,
+                                         reinterpret_cast<uint4 *>(f.ovf + (size_t)blockIdx.x * 2 * FJ_OVF_CAP) + w * FJ_REC_CAP,
+                                         out, a.out_capacity, needs_index);
+            continue;
+        }
         if (RES) fj_count_res(X, ltup, q, okk, c, flo, fhi, fp, run);
         else     fj_count_batch<false, true, N32>(X, G, ltup, q, okk, c, flo, fhi, fp, bm, O);
         // (The failure word is looked at once a unit, not here: an agent-scope load a group made every wave wait for its
@@ -1099,6 +1267,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             if (threadIdx.x == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
+        if (FJ_DBG && threadIdx.x == 0) { FJ_DBG[(size_t)u * 8 + 3] = __builtin_amdgcn_s_memrealtime(); FJ_DBG[(size_t)u * 8 + 7] = fkp ? 1 : 2; }
         if (fkp) continue;                            // the pairs are out, one match each
     }
     // ---- unit total -> chained scan
@@ -1116,13 +1285,13 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 #pragma unroll
     for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
     if (SPEC) {                                       // the other relation probes: the usual unit at the predicted base, emitted at once
-        if (total != spec_total) {                    // (workgroup-uniform)
+        if (total != spec_total || (!RES && unit_needs_index)) {   // (workgroup-uniform; a gathered unit's pairs are out already: nothing left to walk)
             if (threadIdx.x == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         if (threadIdx.x == 0) { a.unit_count[u] = total; sh_base = spec_base; }
         __syncthreads();
-        if (!emitting) continue;
+        if (!emitting || !RES) continue;
         if (!unit_needs_index && !unit_res_dup) {
             if (ovf_total != 0) fj_emit_stream<true, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, MAYRES ? 0u : npatch);
             else                fj_emit_stream<false, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, 0u);
