@@ -181,6 +181,31 @@ int  rhj_last_spec(void);
  * rhj_last_exact(): the last join — 0 not launched, 1 it did the join, 2 it handed over. */
 void rhj_set_exact(int on);
 int  rhj_last_exact(void);
+
+/* ---- several GPUs of one node behind this interface (SURVEY.md 8b "RHJ_DEVICES", 8e; rhjoin.c:42-57: bucket b of R only meets
+ * bucket b of S, so contiguous bucket ranges are independent joins and their pair lists, concatenated in range order, ARE the
+ * canonical result).  rhj_set_devices(n) / env RHJ_DEVICES=n: the library's device (rhj_set_device) and the n - 1 ordinals
+ * behind it, each with a context, stream and workspace of its own inside this one process; -1 when they are not there.
+ * From then on
+ *   RadixHashJoin() with host relations   every device uploads both relations over its own link, joins the d-th of n
+ *                                         equal-width bucket ranges (its first partition pass drops the other buckets while
+ *                                         it reads) and moves its pairs to their place in the one result list; same list,
+ *                                         bit for bit, as on one device;
+ *   rhj_join_devices()                    the same for relations that are already on the devices (one replica each: a
+ *                                         device-resident column store per GPU): device d's pairs stay in out[d];
+ *   rhj_gather_pairs_devices()            the whole list on one of the devices, exact-size peer copies over xGMI — only for a
+ *                                         caller whose next operator lives on that device.
+ * Every device is driven by a host thread of its own; the caller's thread holds the library's lock and waits.  Everything
+ * else (rhj_join_device, Filter, the device-resident intermediate results) stays on the library's own device.
+ * rhj_device_range(): the bucket range device d of n takes at `bits` radix bits (needs no GPU).
+ * Env RHJ_DEVICES_SAME=1 (tests): all n contexts on the library's device — the sharded path at n > 1 on a one-GPU box. */
+int  rhj_set_devices(int n);
+int  rhj_get_devices(void);
+int  rhj_device_range(int bits, int n, int d, uint32_t *lo, uint32_t *hi);
+int  rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *const *d_S, uint64_t nS,
+                      rhj_result_tuple *const *out, const uint64_t *capacity, uint64_t *matches);
+int  rhj_gather_pairs_devices(const rhj_result_tuple *const *lists, const uint64_t *matches, int dst_device,
+                              rhj_result_tuple *dst, uint64_t capacity, uint64_t *total);
 /* Pair order (env RHJ_ORDER=canonical|any).  0 = canonical (default): the reference's order for the
  * radix width in force — bucket ascending, probe side = R iff cR >= cS, probe tuples in input order, build matches
  * in descending position (rhjoin.c:42-57,86,141-250).  1 = any: the same pairs in the canonical order of a radix

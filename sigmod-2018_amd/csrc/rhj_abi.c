@@ -223,10 +223,13 @@ rhj_result_tuple *FindResultTuples(rhj_result *head, int num)
     if (num < 0) return NULL;
     for (; head; head = head->next) {
         if (head->current_load + count > (uint64_t)num) {
-            if (rhj_resident_result(head)) {            /* a copy of the element: the list itself is on the device */
-                static rhj_result_tuple copy;
-                if (rhj_resident_fetch(head, sizeof(rhj_result_tuple), (uint64_t)num - count, &copy)) fatal("FindResultTuples");
-                return &copy;
+            if (rhj_resident_result(head)) {
+                /* a copy of the element (the list itself is on the device), kept in a slot of ITS list: valid until the next
+                 * call on the same list or its FreeResult — elements of two live results do not alias (results.c:126-142
+                 * returns a pointer into the node) */
+                rhj_result_tuple *copy = rhj_resident_slot(head);
+                if (!copy || rhj_resident_fetch(head, sizeof(rhj_result_tuple), (uint64_t)num - count, copy)) fatal("FindResultTuples");
+                return copy;
             }
             return (rhj_result_tuple *)head->buff + ((uint64_t)num - count);
         }

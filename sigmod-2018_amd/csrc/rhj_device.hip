@@ -122,7 +122,16 @@ struct Ctx {
     rhj_stats stats = {};
 };
 
-Ctx g;
+// One context per device.  g_all[0] is the library's context (every entry point of round 1..3 works on it); g_all[1..] belong to
+// the further devices of rhj_set_devices(n) and are only ever touched by the worker threads of a multi-device join, each of
+// which makes its device's context the current one of ITS thread.  `g` stays the name of "the context this thread works on".
+constexpr int MAX_DEVICES = 8;
+Ctx g_all[MAX_DEVICES];
+thread_local Ctx *g_cur = &g_all[0];
+#define g (*g_cur)
+int g_ndev = 1;                      // devices a join is sharded over (rhj_set_devices, env RHJ_DEVICES)
+int g_ndev_env = 0;                  // RHJ_DEVICES as read at load time (applied by the first call that can shard)
+int g_same_device = 0;               // RHJ_DEVICES_SAME=1 (tests): every context on the library's own device — n streams and workspaces on one GPU
 
 // environment defaults are read once at load time; the rhj_set_* calls override them
 struct EnvDefaults {
@@ -130,6 +139,8 @@ struct EnvDefaults {
     {
         const char *e;
         if ((e = getenv("RHJ_DEVICE"))) g.device = atoi(e);
+        if ((e = getenv("RHJ_DEVICES"))) g_ndev_env = atoi(e);
+        if ((e = getenv("RHJ_DEVICES_SAME"))) g_same_device = atoi(e);
         if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 15) g.bits = b; }
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
@@ -1175,6 +1186,86 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
     return 0;
 }
 
+// (on the calling thread's context, without the API lock: the public entry below, and the per-device workers of a multi-device join)
+static int join_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, uint32_t bucket_lo, uint32_t bucket_hi,
+                      rhj_result_tuple *d_out, uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
+{
+    if (matches) *matches = 0;
+    if (ctx_out) *ctx_out = nullptr;
+    if (g.order_any) { fprintf(stderr, "rhj_join_device_range: bucket numbers belong to the caller's radix; not with RHJ_ORDER=any\n"); return -3; }
+    const uint32_t bins = 1u << g.bits;
+    if (bucket_hi > bins) bucket_hi = bins;
+    if (bucket_lo >= bucket_hi) return 0;                     // an empty range joins nothing
+    uint64_t m = 0;
+    const bool whole = bucket_lo == 0 && bucket_hi == bins;
+    g.range_lo = bucket_lo;
+    g.range_span = whole ? 0u : bucket_hi - bucket_lo;        // the whole radix is the ordinary join (small path and all)
+    const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, use_ctx_out, ctx_out, &m);
+    g.range_lo = 0; g.range_span = 0;
+    if (matches) *matches = m;
+    return rc;
+}
+
+// ---- several devices behind the C interface (RHJ_DEVICES; 8e: bucket b of R only meets bucket b of S) ------------
+// The knobs live in the library's own context; the others take them over at the start of every multi-device call.
+static void adopt_knobs(Ctx &d, const Ctx &s)
+{
+    d.bits = s.bits; d.null_on_empty = s.null_on_empty; d.force_hbm = s.force_hbm; d.ablate = s.ablate; d.order_any = s.order_any;
+    d.no_fused = s.no_fused; d.force_fused = s.force_fused; d.no_resident = s.no_resident; d.wide_row_ids = s.wide_row_ids;
+    d.timing = s.timing; d.no_count_in_pass1 = s.no_count_in_pass1; d.no_spec = s.no_spec; d.no_exact = s.no_exact;
+    d.lo_override = s.lo_override; d.no_lowradix = s.no_lowradix; d.no_small = s.no_small; d.small_tiles = s.small_tiles;
+    d.node_pairs = s.node_pairs;
+}
+
+static int set_devices(int n)
+{
+    if (n < 1 || n > MAX_DEVICES) return -1;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return -1;
+    const int base = g_all[0].device;
+    if (!g_same_device && base + n > count) {
+        fprintf(stderr, "rhj_set_devices(%d): devices %d..%d asked for, %d visible\n", n, base, base + n - 1, count);
+        return -1;
+    }
+    for (int d = 1; d < n; ++d) {
+        const int ordinal = g_same_device ? base : base + d;
+        if (g_all[d].ready && g_all[d].device != ordinal) return -1;          // (a context does not move to another device)
+        g_all[d].device = ordinal;
+    }
+    if (!g_same_device)
+        for (int a = 0; a < n; ++a)                                           // best effort: peer copies of pair lists go direct over xGMI
+            for (int b = 0; b < n; ++b)
+                if (a != b && hipSetDevice(base + a) == hipSuccess && hipDeviceEnablePeerAccess(base + b, 0) != hipSuccess) (void)hipGetLastError();
+    (void)hipSetDevice(base);
+    g_ndev = n;
+    return 0;
+}
+
+static int devices_ready()
+{
+    if (g_ndev_env > 1 && g_ndev == 1) { const int want = g_ndev_env; g_ndev_env = 0; return set_devices(want); }
+    return 0;
+}
+
+// the d-th of n contiguous bucket ranges of equal width (shard.equal_ranges: no histogram, no read-back)
+static inline uint32_t range_cut(uint32_t bins, int n, int d) { return (uint32_t)((uint64_t)bins * (uint64_t)d / (uint64_t)n); }
+
+// Runs fn(d) for every device d of the set on a thread of its own whose current context is device d's (d = 0 included: the
+// calling thread holds the API lock and only waits).  One device: on the calling thread.
+template <class F> static void on_devices(int n, F fn)
+{
+    if (n == 1) { fn(0); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n);
+    for (int d = 0; d < n; ++d)
+        pool.emplace_back([d, &fn]() {
+            g_cur = &g_all[d];
+            if (d) adopt_knobs(g_all[d], g_all[0]);
+            fn(d);
+        });
+    for (auto &t : pool) t.join();
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ C-ABI
@@ -1288,18 +1379,68 @@ int rhj_join_device_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_
                           rhj_result_tuple *d_out, uint64_t out_capacity, uint64_t *matches)
 {
     RhjApiLock api_lock;
-    if (matches) *matches = 0;
-    if (g.order_any) { fprintf(stderr, "rhj_join_device_range: bucket numbers belong to the caller's radix; not with RHJ_ORDER=any\n"); return -3; }
-    const uint32_t bins = 1u << g.bits;
-    if (bucket_hi > bins) bucket_hi = bins;
-    if (bucket_lo >= bucket_hi) return 0;                     // an empty range joins nothing
-    uint64_t m = 0;
-    const bool whole = bucket_lo == 0 && bucket_hi == bins;
-    g.range_lo = bucket_lo;
-    g.range_span = whole ? 0u : bucket_hi - bucket_lo;        // the whole radix is the ordinary join (small path and all)
-    const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, false, nullptr, &m);
-    g.range_lo = 0; g.range_span = 0;
-    if (matches) *matches = m;
+    return join_range(d_R, nR, d_S, nS, bucket_lo, bucket_hi, d_out, out_capacity, false, nullptr, matches);
+}
+
+int rhj_set_devices(int n) { RhjApiLock api_lock; g_ndev_env = 0; return set_devices(n); }
+/* the bucket range device d of n joins at `bits` radix bits (no device needed: the planning half of rhj_join_devices) */
+int rhj_device_range(int bits, int n, int d, uint32_t *lo, uint32_t *hi)
+{
+    if (bits < 1 || bits > MAX_BITS || n < 1 || n > MAX_DEVICES || d < 0 || d >= n) return -1;
+    *lo = range_cut(1u << bits, n, d);
+    *hi = range_cut(1u << bits, n, d + 1);
+    return 0;
+}
+int rhj_get_devices(void) { RhjApiLock api_lock; (void)devices_ready(); return g_ndev; }
+
+/* One join over the devices of rhj_set_devices(n).  d_R[d] / d_S[d]: the relations ON device d (replicated: a device-resident
+ * column store per GPU).  Device d joins the d-th of n equal-width bucket ranges with its own context, stream and workspace,
+ * driven by a host thread of its own (rhj_join_device_range's one call per rank, inside one process), and leaves its pairs in
+ * out[d] (capacity[d] of them; matches[d] = their number, the call returns 1 when some list did not fit).  The concatenation
+ * of the lists in device order is the canonical result. */
+int rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *const *d_S, uint64_t nS,
+                     rhj_result_tuple *const *out, const uint64_t *capacity, uint64_t *matches)
+{
+    RhjApiLock api_lock;
+    if (devices_ready()) return -1;
+    const int n = g_ndev;
+    const uint32_t bins = 1u << g_all[0].bits;
+    int rcs[MAX_DEVICES] = {0};
+    try {
+        on_devices(n, [&](int d) {
+            rcs[d] = join_range(d_R[d], nR, d_S[d], nS, range_cut(bins, n, d), range_cut(bins, n, d + 1), out[d], capacity[d], false,
+                                nullptr, &matches[d]);
+        });
+    } catch (...) { return -1; }
+    int rc = 0;
+    for (int d = 0; d < n; ++d) { if (rcs[d] < 0) return rcs[d]; if (rcs[d] > rc) rc = rcs[d]; }
+    return rc;
+}
+
+/* The whole pair list on one device of the set: device d's list (lists[d], matches[d] pairs, as rhj_join_devices left them) is
+ * copied to dst + (the pairs of the devices in front of d) — exact sizes, peer to peer (xGMI), on dst_device's stream.  Only a
+ * caller whose next operator lives on ONE device needs it (north_star: a match list crosses only when its consumer is elsewhere). */
+int rhj_gather_pairs_devices(const rhj_result_tuple *const *lists, const uint64_t *matches, int dst_device, rhj_result_tuple *dst,
+                             uint64_t capacity, uint64_t *total)
+{
+    RhjApiLock api_lock;
+    if (devices_ready() || dst_device < 0 || dst_device >= g_ndev) return -1;
+    uint64_t sum = 0;
+    for (int d = 0; d < g_ndev; ++d) sum += matches[d];
+    if (total) *total = sum;
+    if (sum > capacity) return 1;
+    Ctx *keep = g_cur;
+    g_cur = &g_all[dst_device];
+    int rc = ctx_init();
+    uint64_t at = 0;
+    for (int d = 0; d < g_ndev && !rc; ++d) {
+        if (matches[d] && (lists[d] != dst + at || d != dst_device))
+            if (hipMemcpyPeerAsync(dst + at, g_all[dst_device].device, lists[d], g_all[d].device, matches[d] * sizeof(rhj_result_tuple), g.stream) != hipSuccess) rc = -1;
+        at += matches[d];
+    }
+    if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) rc = -1;
+    g_cur = keep;
+    (void)hipSetDevice(g.device);
     return rc;
 }
 
@@ -1395,15 +1536,13 @@ int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t b
     return *count > capacity ? 1 : 0;
 }
 
-void rhj_release(void)
+static void release_current()
 {
-    RhjApiLock api_lock;
-    rhj_host_pool_release();
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     Buf *all[] = {&g.partR, &g.partS, &g.tmpR, &g.tmpS, &g.cntR, &g.cntS, &g.chunk, &g.histpsum, &g.passhp,
-                  &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.slice_tot, &g.sbase, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
+                  &g.units, &g.bunits, &g.ldsb, &g.meta, &g.summary, &g.ucount, &g.ubase, &g.uflag, &g.bsum, &g.digR, &g.digS, &g.ovf, &g.ovf_base, &g.walk, &g.xrows, &g.lr_tmp, &g.lr_words, &g.lr_status, &g.runR, &g.runS, &g.stripR, &g.stripS, &g.slice_tot, &g.sbase, &g.stash_cnt, &g.stash_row, &g.status, &g.tab32,
                   &g.tab64, &g.inR, &g.inS, &g.out, &g.fcol, &g.fcol_sel, &g.fmask, &g.ftile, &g.fbase, &g.fout};
     for (Buf *b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     for (auto &kv : g.columns) (void)hipFree(kv.second.dev);
@@ -1416,42 +1555,25 @@ void rhj_release(void)
     g.live_blocks.clear();
 }
 
-// ---- host-side staging used by rhj_abi.c (not part of the public header) ----
-
-// Upload both relations, join, and copy the pairs back into `node_pairs`-sized
-// chunks handed to `sink(ctx, chunk_index, ptr_to_fill, pairs)`-allocated memory.
-int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS, uint64_t *matches,
-                  void *(*alloc_chunk)(void *ctx, uint64_t pairs), void *ctx, uint64_t node_pairs)
+void rhj_release(void)
 {
     RhjApiLock api_lock;
-    *matches = 0;
-    if (ctx_init()) return -1;
-    if (nR == 0 || nS == 0) return 0;
-    if (ensure(g.inR, nR * sizeof(rhj_tuple)) || ensure(g.inS, nS * sizeof(rhj_tuple))) return -1;
-    HIP_TRY(hipEventRecord(g.ev_x[0], g.stream));
-    HIP_TRY(hipMemcpyAsync(g.inR.p, R, nR * sizeof(rhj_tuple), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.inS.p, S, nS * sizeof(rhj_tuple), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipEventRecord(g.ev_x[1], g.stream));
-    rhj_result_tuple *d_out = nullptr;
-    uint64_t M = 0;
-    const int rc = join_device((const rhj_tuple *)g.inR.p, nR, (const rhj_tuple *)g.inS.p, nS, nullptr, 0, true, &d_out, &M);
-    if (rc < 0) return rc;
-    g.stats.ms_h2d = ev_ms(g.ev_x[0], g.ev_x[1]);
-    *matches = M;
+    rhj_host_pool_release();
+    Ctx *keep = g_cur;
+    for (int d = MAX_DEVICES - 1; d >= 0; --d) { g_cur = &g_all[d]; release_current(); }   // (the library's own device last: it stays current)
+    g_cur = keep;
+}
+
+// ---- host-side staging used by rhj_abi.c (not part of the public header) ----
+
+// The pairs of the calling thread's context, [d_out, d_out + M), into the caller-visible nodes as elements [base, base + M) of the
+// list.  The nodes are plain malloc memory (FreeResult = free(buff); free(node), results.c:144-153): freshly mapped pages, so
+// whoever writes them first pays the page faults — a single thread filling them measured 5.8 GB/s (44 ms for 256 MB).  All
+// nodes are allocated up front (untouched), the pairs come through a ring of pinned staging blocks (the copy of block i+1..
+// runs while block i is moved), and every block is moved into the nodes by several host threads, each faulting in its own pages.
+static int pairs_to_nodes(const rhj_result_tuple *d_out, uint64_t base, uint64_t M, uint64_t node_pairs, char *const *nodes, unsigned nthreads)
+{
     if (M == 0) return 0;
-    if (node_pairs == 0) node_pairs = M;
-    // D2H.  The caller-visible nodes are plain malloc memory (FreeResult = free(buff); free(node), results.c:144-153):
-    // freshly mapped pages, so whoever writes them first pays the page faults — a single thread filling them measured
-    // 5.8 GB/s (44 ms for 256 MB).  All nodes are allocated up front (untouched), the pairs come through a ring of pinned
-    // staging blocks (the copy of block i+1.. runs while block i is moved), and every block is moved into the nodes by
-    // several host threads, each faulting in its own pages.
-    const uint64_t nnodes = (M + node_pairs - 1) / node_pairs;
-    std::vector<char *> nodes((size_t)nnodes);
-    for (uint64_t i = 0; i < nnodes; ++i) {
-        const uint64_t cnt = M - i * node_pairs < node_pairs ? M - i * node_pairs : node_pairs;
-        nodes[(size_t)i] = (char *)alloc_chunk(ctx, cnt);
-        if (!nodes[(size_t)i]) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)cnt); return -1; }
-    }
     constexpr int RING = 4;
     const uint64_t blk = (uint64_t)1 << 20;                               // pairs per staging block (16 MiB)
     if (!g.pin_ring[0]) {
@@ -1461,28 +1583,81 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
         }
     }
     HIP_TRY(hipEventRecord(g.ev_x[2], g.stream));
-    unsigned nthreads = std::thread::hardware_concurrency();
-    if (nthreads > 8) nthreads = 8;
     if (nthreads < 1 || M * sizeof(rhj_result_tuple) < ((size_t)8 << 20)) nthreads = 1;
-    // the ring protocol and the mover threads are host-only code (rhj_host.cpp: rhj_move_blocks, built and run under the
+    // the ring protocol and the mover threads are host-only code (rhj_host.cpp: rhj_move_blocks_at, built and run under the
     // sanitizers on the CPU); this side only starts the copy of a block and waits for it
-    struct Copy { const rhj_result_tuple *d_out; uint64_t M, blk; } cp = {d_out, M, blk};
+    struct Copy { const rhj_result_tuple *d_out; uint64_t M, blk; Ctx *c; } cp = {d_out, M, blk, g_cur};
     auto issue = [](void *c, uint64_t b) -> int {
         const Copy *k = (const Copy *)c;
         const uint64_t cnt = k->M - b * k->blk < k->blk ? k->M - b * k->blk : k->blk;
-        if (hipMemcpyAsync(g.pin_ring[b % RING], k->d_out + b * k->blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, g.stream) != hipSuccess) return -1;
-        return hipEventRecord(g.ev_ring[b % RING], g.stream) == hipSuccess ? 0 : -1;
+        if (hipMemcpyAsync(k->c->pin_ring[b % RING], k->d_out + b * k->blk, cnt * sizeof(rhj_result_tuple), hipMemcpyDeviceToHost, k->c->stream) != hipSuccess) return -1;
+        return hipEventRecord(k->c->ev_ring[b % RING], k->c->stream) == hipSuccess ? 0 : -1;
     };
-    auto landed = [](void *, uint64_t b) -> int { return hipEventSynchronize(g.ev_ring[b % RING]) == hipSuccess ? 0 : -1; };
+    auto landed = [](void *c, uint64_t b) -> int { return hipEventSynchronize(((const Copy *)c)->c->ev_ring[b % RING]) == hipSuccess ? 0 : -1; };
     char *staging[RING];
     for (int i = 0; i < RING; ++i) staging[i] = (char *)g.pin_ring[i];
-    if (rhj_move_blocks(M, sizeof(rhj_result_tuple), node_pairs, nodes.data(), blk, RING, staging, nthreads, issue, landed, &cp)) {
+    if (rhj_move_blocks_at(base, M, sizeof(rhj_result_tuple), node_pairs, nodes, blk, RING, staging, nthreads, issue, landed, &cp)) {
         (void)hipGetLastError();
         return -1;
     }
     HIP_TRY(hipEventRecord(g.ev_x[3], g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     g.stats.ms_d2h = ev_ms(g.ev_x[2], g.ev_x[3]);
+    return 0;
+}
+
+// Upload both relations, join, and copy the pairs back into `node_pairs`-sized
+// chunks handed to `sink(ctx, chunk_index, ptr_to_fill, pairs)`-allocated memory.
+// With rhj_set_devices(n > 1) / RHJ_DEVICES: every device uploads both relations over its own link, joins the d-th of n
+// equal-width bucket ranges (the first partition pass drops the others while it reads), and its pairs go to their place in the
+// list — behind the pairs of the devices in front of it — over its own link again: n uploads side by side, 1/n of the kernel
+// work and of the read-back each.
+int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS, uint64_t *matches,
+                  void *(*alloc_chunk)(void *ctx, uint64_t pairs), void *ctx, uint64_t node_pairs)
+{
+    RhjApiLock api_lock;
+    *matches = 0;
+    if (devices_ready()) return -1;
+    if (ctx_init()) return -1;
+    if (nR == 0 || nS == 0) return 0;
+    const int n = g_all[0].order_any ? 1 : g_ndev;             // (bucket ranges belong to the caller's radix: not with RHJ_ORDER=any)
+    const uint32_t bins = 1u << g_all[0].bits;
+    int rcs[MAX_DEVICES] = {0};
+    uint64_t Ms[MAX_DEVICES] = {0};
+    rhj_result_tuple *d_outs[MAX_DEVICES] = {nullptr};
+    auto upload_and_join = [&](int d) {
+        rcs[d] = -1;
+        if (ctx_init()) return;
+        if (ensure(g.inR, nR * sizeof(rhj_tuple)) || ensure(g.inS, nS * sizeof(rhj_tuple))) return;
+        if (hipEventRecord(g.ev_x[0], g.stream) != hipSuccess ||
+            hipMemcpyAsync(g.inR.p, R, nR * sizeof(rhj_tuple), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+            hipMemcpyAsync(g.inS.p, S, nS * sizeof(rhj_tuple), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+            hipEventRecord(g.ev_x[1], g.stream) != hipSuccess) return;
+        if (n == 1) rcs[d] = join_device((const rhj_tuple *)g.inR.p, nR, (const rhj_tuple *)g.inS.p, nS, nullptr, 0, true, &d_outs[d], &Ms[d]);
+        else        rcs[d] = join_range((const rhj_tuple *)g.inR.p, nR, (const rhj_tuple *)g.inS.p, nS, range_cut(bins, n, d), range_cut(bins, n, d + 1),
+                                        nullptr, 0, true, &d_outs[d], &Ms[d]);
+        if (rcs[d] >= 0) g.stats.ms_h2d = ev_ms(g.ev_x[0], g.ev_x[1]);
+    };
+    try { on_devices(n, upload_and_join); } catch (...) { return -1; }
+    uint64_t M = 0, base[MAX_DEVICES] = {0};
+    for (int d = 0; d < n; ++d) { if (rcs[d] < 0) return rcs[d]; base[d] = M; M += Ms[d]; }
+    *matches = M;
+    if (M == 0) return 0;
+    if (node_pairs == 0) node_pairs = M;
+    const uint64_t nnodes = (M + node_pairs - 1) / node_pairs;
+    std::vector<char *> nodes((size_t)nnodes);
+    for (uint64_t i = 0; i < nnodes; ++i) {
+        const uint64_t cnt = M - i * node_pairs < node_pairs ? M - i * node_pairs : node_pairs;
+        nodes[(size_t)i] = (char *)alloc_chunk(ctx, cnt);
+        if (!nodes[(size_t)i]) { fprintf(stderr, "rhj: out of host memory for %llu result pairs\n", (unsigned long long)cnt); return -1; }
+    }
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 8) nthreads = 8;
+    nthreads = nthreads / (unsigned)n ? nthreads / (unsigned)n : 1u;      // the devices' movers share the host's cores
+    try {
+        on_devices(n, [&](int d) { rcs[d] = pairs_to_nodes(d_outs[d], base[d], Ms[d], node_pairs, nodes.data(), nthreads); });
+    } catch (...) { return -1; }
+    for (int d = 0; d < n; ++d) if (rcs[d]) return -1;
     return 0;
 }
 

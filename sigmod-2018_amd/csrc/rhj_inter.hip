@@ -13,6 +13,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -160,7 +161,11 @@ __global__ __launch_bounds__(256) void k_count_flags(const uint8_t *flags, uint6
     if (threadIdx.x == 0) atomicAdd(count, part[0] + part[1] + part[2] + part[3]);
 }
 
-std::unordered_set<const void *> g_rel, g_res, g_inter;
+std::unordered_set<const void *> g_rel, g_inter;
+// resident result nodes, each with the host slot FindResultTuples hands out for it (a pointer into the list is what results.c
+// returns; the list is on the device here, so the caller gets a copy that lives as long as the list — one per list, so that
+// elements of two live results do not alias)
+std::unordered_map<const void *, rhj_result_tuple> g_res;
 
 // RHJ_TRACE=1: one line per call on stderr (which operator, which relations, how many rows)
 bool tracing() { static const bool on = getenv("RHJ_TRACE") != nullptr; return on; }
@@ -210,7 +215,7 @@ rhj_result *make_result(void *dbuff, uint64_t count)
     r->buff = (char *)dbuff;
     r->next = nullptr;
     r->current_load = count;
-    g_res.insert(r);
+    g_res.emplace(r, rhj_result_tuple{0, 0});
     return r;
 }
 
@@ -360,10 +365,12 @@ int rhj_sum_views_device(int views, const uint64_t *const *d_cols, const uint64_
     if (views <= 0) return 0;
     if (views > SUM_VIEWS) return -1;
     hipStream_t s = stream();
-    if (!d_words) {
-        if (hipMalloc((void **)&d_words, (SUM_VIEWS + 1) * 8) != hipSuccess) return -1;
-        if (hipHostMalloc((void **)&h_words, SUM_VIEWS * 8, hipHostMallocDefault) != hipSuccess) return -1;
-        if (hipMemsetAsync(d_words, 0, (SUM_VIEWS + 1) * 8, s) != hipSuccess) return -1;
+    if (!d_words) {                                   // both blocks and the cleared words, or nothing: published only when all three calls went through
+        unsigned long long *d = nullptr, *h = nullptr;
+        if (hipMalloc((void **)&d, (SUM_VIEWS + 1) * 8) != hipSuccess) return -1;
+        if (hipHostMalloc((void **)&h, SUM_VIEWS * 8, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); return -1; }
+        if (hipMemsetAsync(d, 0, (SUM_VIEWS + 1) * 8, s) != hipSuccess) { (void)hipFree(d); (void)hipHostFree(h); return -1; }
+        d_words = d; h_words = h;
     }
     SumViews v;
     uint64_t most = 0;
@@ -375,7 +382,14 @@ int rhj_sum_views_device(int views, const uint64_t *const *d_cols, const uint64_
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_sum_views, dim3((unsigned)blocks, (unsigned)views), dim3(256), 0, s, v, d_words, (uint32_t *)(d_words + SUM_VIEWS), h_words);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        // the kernel's last block out leaves the words zero for the next call; after a failed launch or wait nobody did
+        if (hipMemsetAsync(d_words, 0, (SUM_VIEWS + 1) * 8, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            (void)hipFree(d_words); (void)hipHostFree(h_words);
+            d_words = nullptr; h_words = nullptr;             // (start over on the next call)
+        }
+        return -1;
+    }
     for (int i = 0; i < views; ++i) sums[i] = ((volatile unsigned long long *)h_words)[i];
     return 0;
 }
@@ -462,6 +476,14 @@ void rhj_resident_free_relation(rhj_relation *rel)
     g_rel.erase(rel);
     rhj_dev_free(rel->tuples);
     free(rel);
+}
+
+// the host copy of the element FindResultTuples last fetched from this resident list (unordered_map nodes do not move)
+rhj_result_tuple *rhj_resident_slot(const rhj_result *res)
+{
+    RhjApiLock api_lock;
+    auto it = g_res.find(res);
+    return it == g_res.end() ? nullptr : &it->second;
 }
 
 // element `index` of a resident result, for the results.c accessors (results.c:48-64, :126-142)
@@ -863,14 +885,22 @@ static const RelationFileHeader *map_relation_file(rhj_relation_listnode *node, 
     node->fd = open(node->filename, O_RDONLY);
     if (node->fd < 0) return nullptr;
     struct stat info;
-    if (fstat(node->fd, &info) != 0 || (size_t)info.st_size < sizeof(RelationFileHeader)) return nullptr;
-    void *base = mmap(nullptr, (size_t)info.st_size, PROT_READ, MAP_PRIVATE, node->fd, 0);
-    if (base == MAP_FAILED) { fprintf(stderr, "rhj: cannot map relation file %s\n", node->filename); return nullptr; }
-    const RelationFileHeader *h = static_cast<const RelationFileHeader *>(base);
-    if (h->columns != 0 && (size_t)info.st_size - sizeof(RelationFileHeader) < h->rows * h->columns * sizeof(uint64_t)) {
-        fprintf(stderr, "rhj: relation file %s is shorter than its header says\n", node->filename);
-        return nullptr;
+    void *base = MAP_FAILED;
+    const RelationFileHeader *h = nullptr;
+    if (fstat(node->fd, &info) == 0 && (size_t)info.st_size >= sizeof(RelationFileHeader))
+        base = mmap(nullptr, (size_t)info.st_size, PROT_READ, MAP_PRIVATE, node->fd, 0);
+    if (base == MAP_FAILED) fprintf(stderr, "rhj: cannot map relation file %s\n", node->filename);
+    else {
+        h = static_cast<const RelationFileHeader *>(base);
+        // rows x columns x 8 bytes behind the header, without trusting the product of two 64-bit words of the file not to wrap
+        const uint64_t words = ((uint64_t)info.st_size - sizeof(RelationFileHeader)) / sizeof(uint64_t);
+        if (h->columns != 0 && h->rows > words / h->columns) {
+            fprintf(stderr, "rhj: relation file %s is shorter than its header says\n", node->filename);
+            munmap(base, (size_t)info.st_size);
+            h = nullptr;
+        }
     }
+    if (h == nullptr) { close(node->fd); node->fd = -1; return nullptr; }   // nothing of a refused file stays open or mapped
     *bytes = (size_t)info.st_size;
     return h;
 }

@@ -37,6 +37,9 @@ void rhj_api_unlock(void);
 int rhj_move_blocks(uint64_t total, uint64_t elem, uint64_t node_elems, char *const *nodes, uint64_t blk, int ring,
                     char *const *staging, unsigned threads, int (*issue)(void *ctx, uint64_t b),
                     int (*wait)(void *ctx, uint64_t b), void *ctx);
+int rhj_move_blocks_at(uint64_t base, uint64_t total, uint64_t elem, uint64_t node_elems, char *const *nodes, uint64_t blk, int ring,
+                       char *const *staging, unsigned threads, int (*issue)(void *ctx, uint64_t b),
+                       int (*wait)(void *ctx, uint64_t b), void *ctx);
 
 /* device-resident side of the reference's entry points (rhj_inter.hip), called by rhj_abi.c */
 rhj_result *rhj_resident_join(rhj_relation *relR, rhj_relation *relS);
@@ -44,6 +47,7 @@ rhj_result *rhj_resident_filter(rhj_inter_res *head, rhj_filter_pred *filter_p, 
 void rhj_resident_free_result(rhj_result *res);
 void rhj_resident_free_relation(rhj_relation *rel);
 int  rhj_resident_fetch(const rhj_result *res, uint64_t elem_bytes, uint64_t index, void *dst);
+rhj_result_tuple *rhj_resident_slot(const rhj_result *res);   /* per-list host copy of the element FindResultTuples returns */
 #ifdef __cplusplus
 }
 struct RhjApiLock {

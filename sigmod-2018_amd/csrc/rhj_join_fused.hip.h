@@ -1001,36 +1001,60 @@ __device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<
         }
     }
     uint32_t ne = 0;                                   // records of this group so far (wave-uniform)
+    // FJ_SER candidates a lane and step: which candidates a lane walks is a matter of the index alone (LDS), so their gathers are
+    // issued together and verified in order afterwards — the chain of a group is steps x one gather latency
+#ifndef FJ_SER
+#define FJ_SER 1                                   // (2 and 3 measured the same on C3: it is not this chain that sets the pace)
+#endif
     for (;;) {
-        uint32_t ks = V;                               // the first of the lane's tuples with a candidate left
+        uint32_t ks[FJ_SER], kx[FJ_SER], ky[FJ_SER], pr[FJ_SER], p[FJ_SER];
 #pragma unroll
-        for (int k = V - 1; k >= 0; --k)
-            if ((tm[k] & 0xffu) != 0 || (sn[k] >> 16) > (uint32_t)FJ_WIN) ks = (uint32_t)k;
-        if (__ballot(ks < (uint32_t)V) == 0) break;
-        uint32_t s_ = sn[0], t_ = tm[0], kx = qx[0], ky = qy[0], pr = qz[0], cc = c[0];
+        for (int j = 0; j < FJ_SER; ++j) {
+            ks[j] = V;                                 // the first of the lane's tuples with a candidate left
 #pragma unroll
-        for (int k = 1; k < V; ++k)
-            if (ks == (uint32_t)k) { s_ = sn[k]; t_ = tm[k]; kx = qx[k]; ky = qy[k]; pr = qz[k]; cc = c[k]; }
-        uint32_t p = 0xffffffffu;
-        if (ks < (uint32_t)V) {
-            if ((t_ & 0xffu) == 0) {                   // the window is used up and the slot goes on
-                s_ += (uint32_t)FJ_WIN - ((uint32_t)FJ_WIN << 16);
-                t_ |= fj_window(X, s_ & 0xffffu, s_ >> 16, t_ & 0xffff0000u);
+            for (int k = V - 1; k >= 0; --k)
+                if ((tm[k] & 0xffu) != 0 || (sn[k] >> 16) > (uint32_t)FJ_WIN) ks[j] = (uint32_t)k;
+            uint32_t s_ = sn[0], t_ = tm[0];
+            kx[j] = qx[0]; ky[j] = qy[0]; pr[j] = qz[0];
+#pragma unroll
+            for (int k = 1; k < V; ++k)
+                if (ks[j] == (uint32_t)k) { s_ = sn[k]; t_ = tm[k]; kx[j] = qx[k]; ky[j] = qy[k]; pr[j] = qz[k]; }
+            p[j] = 0xffffffffu;
+            if (ks[j] < (uint32_t)V) {
+                if ((t_ & 0xffu) == 0) {               // the window is used up and the slot goes on
+                    s_ += (uint32_t)FJ_WIN - ((uint32_t)FJ_WIN << 16);
+                    t_ |= fj_window(X, s_ & 0xffffu, s_ >> 16, t_ & 0xffff0000u);
+                }
+                const uint32_t m = t_ & 0xffu;
+                if (m != 0) { p[j] = X.ent[(s_ & 0xffffu) + (uint32_t)__builtin_ctz(m)] & 0xffffu; t_ &= t_ - 1u; }
             }
-            const uint32_t m = t_ & 0xffu;
-            if (m != 0) { p = X.ent[(s_ & 0xffffu) + (uint32_t)__builtin_ctz(m)] & 0xffffu; t_ &= t_ - 1u; }
-        }
-        const uint4 g = p != 0xffffffffu ? G.load(p) : make_uint4(0, 0, 0, 0);
-        const bool eq = p != 0xffffffffu && g.x == kx && g.y == ky;
-        const bool isrec = eq && cc != 0;
-        const uint64_t mk = __ballot(isrec);
-        const uint32_t slot = ne + (uint32_t)__popcll(mk & lt);
-        if (isrec && slot < FJ_REC_CAP) rec[slot] = make_uint4(g.z, pr, (ks * WAVE + lane) | (cc << 8), 0u);
-        ne += (uint32_t)__popcll(mk);
-        cannot = cannot || (eq && cc >= 255u);         // (the ordinal has eight bits)
 #pragma unroll
-        for (int k = 0; k < V; ++k)
-            if (ks == (uint32_t)k) { sn[k] = s_; tm[k] = t_; if (eq) { if (cc == 0) first[k] = g.z; c[k] = cc + 1u; } }
+            for (int k = 0; k < V; ++k)
+                if (ks[j] == (uint32_t)k) { sn[k] = s_; tm[k] = t_; }
+        }
+        if (__ballot(ks[0] < (uint32_t)V) == 0) break;
+#ifdef FJ_ABL_NOSER          // timing experiment only (wrong results): second and later candidates are not fetched
+        continue;
+#endif
+        uint4 g[FJ_SER];
+#pragma unroll
+        for (int j = 0; j < FJ_SER; ++j) g[j] = p[j] != 0xffffffffu ? G.load(p[j]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < FJ_SER; ++j) {
+            uint32_t cc = c[0];
+#pragma unroll
+            for (int k = 1; k < V; ++k) if (ks[j] == (uint32_t)k) cc = c[k];
+            const bool eq = p[j] != 0xffffffffu && g[j].x == kx[j] && g[j].y == ky[j];
+            const bool isrec = eq && cc != 0;
+            const uint64_t mk = __ballot(isrec);
+            const uint32_t slot = ne + (uint32_t)__popcll(mk & lt);
+            if (isrec && slot < FJ_REC_CAP) rec[slot] = make_uint4(g[j].z, pr[j], (ks[j] * WAVE + lane) | (cc << 8), 0u);
+            ne += (uint32_t)__popcll(mk);
+            cannot = cannot || (eq && cc >= 255u);     // (the ordinal has eight bits)
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (ks[j] == (uint32_t)k && eq) { if (cc == 0) first[k] = g[j].z; c[k] = cc + 1u; }
+        }
     }
     cannot = cannot || ne > FJ_REC_CAP;
     uint32_t off[V], wrun = 0, cs = 0;
@@ -1041,7 +1065,11 @@ __device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<
         wrun += tot;
         cs += c[k];
     }
+#ifdef FJ_ABL_NOLB           // timing experiment only (wrong results): no chained scan, every group writes at its own 256 slots
+    const uint64_t wbase = spec_base + (uint64_t)grp * 256u;
+#else
     const uint64_t wbase = spec_base + fj_group_lookback(gpre, grp, wrun, lane);
+#endif
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const uint64_t at = wbase + off[k];
@@ -1201,7 +1229,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         }
         O.gid = grp;
         uint32_t run[FJ_V], bm[FJ_V];
-        if (SPEC && !fkp && !RES) {
+        if (SPEC && !MAYRES && !fkp) {                 // (MAYRES kernels — C4's — keep the stash for such units: this code's live values pushed their resident loops into scratch)
             // SPEC, the OTHER relation probes a gathered build side: the unit's first pair is known (the hypothesis' relation's
             // psum), so all a group needs is the match total of the groups in front of it — a chained scan among the waves of
             // this workgroup, in LDS — and its pairs go out from here (fj_group_direct): no stash, no emit pass.
@@ -1285,13 +1313,17 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 #pragma unroll
     for (int i = 0; i < FJ_WAVES; ++i) total += wsum[i];
     if (SPEC) {                                       // the other relation probes: the usual unit at the predicted base, emitted at once
-        if (total != spec_total || (!RES && unit_needs_index)) {   // (workgroup-uniform; a gathered unit's pairs are out already: nothing left to walk)
+#ifdef FJ_ABL_NOSER
+        if (false) {
+#else
+        if (total != spec_total || (!MAYRES && unit_needs_index)) {
+#endif   // (workgroup-uniform; a gathered unit's pairs are out already: nothing left to walk)
             if (threadIdx.x == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         if (threadIdx.x == 0) { a.unit_count[u] = total; sh_base = spec_base; }
         __syncthreads();
-        if (!emitting || !RES) continue;
+        if (!emitting || !MAYRES) continue;
         if (!unit_needs_index && !unit_res_dup) {
             if (ovf_total != 0) fj_emit_stream<true, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, MAYRES ? 0u : npatch);
             else                fj_emit_stream<false, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, 0u);

@@ -26,6 +26,7 @@ rhj_result *rhj_resident_filter(rhj_inter_res *, rhj_filter_pred *, rhj_relation
 void rhj_resident_free_result(rhj_result *) {}
 void rhj_resident_free_relation(rhj_relation *) {}
 int rhj_resident_fetch(const rhj_result *, uint64_t, uint64_t, void *) { return -1; }
+rhj_result_tuple *rhj_resident_slot(const rhj_result *) { return nullptr; }
 
 struct FakeCopy { const rhj_result_tuple *src; uint64_t total, blk; char *const *staging; int ring; };
 static int fake_issue(void *c, uint64_t b)

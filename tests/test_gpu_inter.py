@@ -283,6 +283,36 @@ def test_scripted_plans_match_the_reference_host_code(mod, rhj):
             e.L.FreeInterResults(e.head)
 
 
+def test_find_result_tuples_of_two_live_resident_results_do_not_alias(mod, rhj):
+    """FindResultTuples (results.c:126-142) returns a pointer into the list; a device-resident list hands out a host copy of
+    the element instead — one slot per list, so an element of one result stays what it was while another result is read."""
+    lib = rhj.lib
+    P = C.POINTER
+    rng = np.random.default_rng(5)
+    rels = [[rng.permutation(2000).astype(np.uint64)], [rng.permutation(2000).astype(np.uint64)]]
+    rm, keep = make_map(mod, rels)
+    e = Engine(mod, lib, rhj)
+    q = (C.c_int * 2)(0, 1)
+    lib.InitInterResults(C.byref(e.head), 2)
+    lib.FindResultTuples.argtypes = [P(mod.Result), C.c_int]
+    lib.FindResultTuples.restype = P(C.c_uint64)
+    relR, relS = lib.GetRelation(0, 0, e.head, rm, q), lib.GetRelation(1, 0, e.head, rm, q)
+    a, b = lib.RadixHashJoin(relR, relS, None), lib.RadixHashJoin(relS, relR, None)
+    assert lib.GetResultNum(a) == 2000 and lib.GetResultNum(b) == 2000
+    pa = lib.FindResultTuples(a, 17)
+    va = (pa[0], pa[1])
+    pb = lib.FindResultTuples(b, 1234)
+    assert C.addressof(pa.contents) != C.addressof(pb.contents)
+    assert (pa[0], pa[1]) == va and rels[0][0][va[0]] == rels[1][0][va[1]]
+    assert rels[1][0][pb[0]] == rels[0][0][pb[1]]
+    assert not lib.FindResultTuples(a, 2000) and not lib.FindResultTuples(a, -1)
+    for r in (relR, relS):
+        lib.FreeRelation(r)
+    for r in (a, b):
+        lib.FreeResult(r)
+    lib.FreeInterResults(e.head)
+
+
 def test_self_join_inactive_and_active_relation(mod, rhj):
     """SelfJoin (inter_res.c:234-263) in its intended semantics (:252 reads map[given_rel]
     instead of map[query_relations[given_rel]], :259 pushes a table pointer instead of the row position) against a

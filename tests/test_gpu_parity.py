@@ -404,18 +404,43 @@ def test_fuzz_shapes_bits_paths(rhj, oracle):
     assert (dev_join(rhj, R, S) == oracle.join(R, S, 4)).all()
 
 
+def _full_size_both_kernels(rhj, name, seed, want_spec, fk=True):
+    """One BASELINE workload at full size through the size-independent properties — twice: with the foreign-key speculation
+    (k_join_spec; rhj_last_spec() says whether it held, so a silent fall-through to the ordinary kernel cannot pass) and with
+    it switched off (k_join_fused); the two pair lists must be the same bytes."""
+    import bench
+    torch = rhj.torch
+    w = bench.WORKLOADS[name]
+    rhj.set_bits(w["bits"])
+    R, S = bench.make_relations(w, rhj.dev, seed)
+    try:
+        rhj.lib.rhj_set_spec(1)
+        t, m = rhj.join_device(R, S, capacity=w["nS"])
+        assert rhj.lib.rhj_last_spec() == want_spec, "speculation: %d (0 not tried, 1 held, 2 failed)" % rhj.lib.rhj_last_spec()
+        bench.check_properties(R, S, t, m, w, fk=fk)
+        rhj.lib.rhj_set_spec(0)
+        t0, m0 = rhj.join_device(R, S, capacity=w["nS"])
+        assert rhj.lib.rhj_last_spec() == 0
+        assert m0 == m and torch.equal(t[:m], t0[:m]), "the speculative and the ordinary kernel disagree"
+        del t0
+    finally:
+        rhj.lib.rhj_set_spec(1)
+    del R, S, t
+    torch.cuda.empty_cache()
+
+
 def test_full_size_properties_c3(rhj):
     """BASELINE config 3 (100M x 100M uniform FK, 12 radix bits) at full size through the
     size-independent properties (the oracle would need minutes): one pair per S tuple, equal keys,
-    S row ids a permutation, buckets ascending."""
-    import bench
-    w = bench.WORKLOADS["c3"]
-    rhj.set_bits(w["bits"])
-    R, S = bench.make_relations(w, rhj.dev, 99)
-    t, m = rhj.join_device(R, S, capacity=w["nS"])
-    bench.check_properties(R, S, t, m, w)
-    del R, S, t
-    rhj.torch.cuda.empty_cache()
+    S row ids a permutation, buckets ascending, the canonical order inside the buckets — by k_join_spec (the
+    speculation must have held) and by k_join_fused, bit for bit the same."""
+    _full_size_both_kernels(rhj, "c3", 99, 1)
+
+
+def test_full_size_properties_c3_where_the_speculation_fails(rhj):
+    """The same 100M x 100M join with half of S without a partner (bench.py --workload c3half): the speculation is tried,
+    fails its checks on the device and hands over inside the call; the result is the ordinary kernel's."""
+    _full_size_both_kernels(rhj, "c3half", 98, 2, fk=False)
 
 
 def test_first_call_in_fresh_process_takes_the_fallback(oracle):
@@ -447,18 +472,12 @@ print("ok")
 
 def test_full_size_properties_c4(rhj):
     """BASELINE config 4 (100M x 1B Zipf(0.9) FK, 14 radix bits: LDS-resident units, skewed buckets split
-    into many units) at full size through the size-independent properties."""
-    import bench
+    into many units) at full size through the size-independent properties, by k_join_spec<resident> (held) and by
+    k_join_fused<resident>, bit for bit the same."""
     free, _ = rhj.torch.cuda.mem_get_info()
-    if free < 110 * (1 << 30):
-        pytest.skip("needs ~80 GB of device memory")
-    w = bench.WORKLOADS["c4"]
-    rhj.set_bits(w["bits"])
-    R, S = bench.make_relations(w, rhj.dev, 7)
-    t, m = rhj.join_device(R, S, capacity=w["nS"])
-    bench.check_properties(R, S, t, m, w)
-    del R, S, t
-    rhj.torch.cuda.empty_cache()
+    if free < 130 * (1 << 30):
+        pytest.skip("needs ~100 GB of device memory")
+    _full_size_both_kernels(rhj, "c4", 7, 1)
 
 
 def test_above_2_31_tuples(rhj):

@@ -89,6 +89,24 @@ def test_scheduler_tokens_and_knobs(lib):
     assert b"gfx950" in lib.rhj_version()
 
 
+def test_device_ranges_are_the_sharding_modules_equal_ranges(lib):
+    """rhj_device_range (the planning half of rhj_join_devices / RHJ_DEVICES: which buckets device d of n joins) against
+    shard.equal_ranges, the ranges the torch.distributed path and its gloo tests use: contiguous, complete, equal width."""
+    shard = importlib.import_module("sigmod-2018_amd.shard")
+    lo, hi = C.c_uint32(0), C.c_uint32(0)
+    for bits in range(1, 16):
+        for n in range(1, 9):
+            got = []
+            for d in range(n):
+                assert lib.rhj_device_range(bits, n, d, C.byref(lo), C.byref(hi)) == 0
+                got.append((lo.value, hi.value))
+            assert got == shard.equal_ranges(bits, n), (bits, n)
+            assert got[0][0] == 0 and got[-1][1] == 1 << bits and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    assert lib.rhj_device_range(4, 9, 0, C.byref(lo), C.byref(hi)) == -1       # at most eight devices
+    assert lib.rhj_device_range(4, 2, 2, C.byref(lo), C.byref(hi)) == -1
+    assert lib.rhj_device_range(16, 2, 0, C.byref(lo), C.byref(hi)) == -1
+
+
 def test_order_mode_and_its_radix_rule(lib):
     """rhj_set_order / rhj_get_order and the width order mode "any" picks (include/rhj.h): build sides of ~16 K tuples per
     bucket on comparable sizes, ~6.5 K when the probe side is four times the build side or more, and for small relations
