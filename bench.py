@@ -57,6 +57,19 @@ WORKLOADS = {
 }
 
 
+def source_fingerprint():
+    """sha256 (16 hex digits) over the library's sources: what a profile was collected on, comparable where there is no .git (the GPU box)"""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sigmod-2018_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "sigmod-2018_amd", "csrc", "*.c*")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if f.endswith(".o") or f.endswith(".s"):
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def lsr(x, k):
     """logical shift right on int64 tensors"""
     return (x >> k) & ((1 << (64 - k)) - 1)
@@ -634,9 +647,14 @@ def main():
                         else "k_join_fused on the finer buckets + k_lr_totals + k_lr_emit (internal join, then the pairs in the canonical order "
                              "of the caller's radix: the whole probe phase of the low-radix path)" if lowradix
                         else "k_probe<WRITE> (emit pass of the tiled path)")
-        # HBM-side bytes of the dominant kernel per launch: rocprofv3 --pmc passes of this same command,
-        # committed under profiles/ (tools/pmc.sh; counters cannot be read from inside this process)
-        traffic, traffic_src = None, None
+        # HBM-side bytes of the dominant kernel per launch: rocprofv3 --pmc passes of this same command, committed under profiles/
+        # (tools/pmc.sh; counters cannot be read from inside this process), RAW and CORRECTED by the calibration of
+        # profiles/r04_calibration.json (tools/micro/calib.hip: known byte counts in this kernel's own access patterns):
+        #   streaming reads of 8, 12 and 16 B a lane: FETCH_SIZE = exactly half of the lines they touch  -> x 2
+        #   stores: WRITE_SIZE exact
+        #   the 12-byte sc1 gathers: every one that misses the L2s is one 64-byte request, counted as it is
+        # so  corrected = stream lines (known by construction: both partitioned relations once) + (raw FETCH - stream lines / 2) + WRITE.
+        traffic, traffic_src, traffic_detail = None, None, None
         try:
             import glob
             cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.workload)) if "subsplit" not in f)
@@ -647,15 +665,33 @@ def main():
                 for kname, kv in pm.items():
                     if isinstance(kv, dict) and any(wk in kname for wk in want) and "FETCH_SIZE" in kv and "WRITE_SIZE" in kv:
                         key = [wk for wk in want if wk in kname][0]
-                        per[key] = max(per.get(key, 0), int((kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) * 1024))   # max: the instantiation that ran
+                        if (kv["FETCH_SIZE"] + kv["WRITE_SIZE"]) > sum(per.get(key, (0, 0))):                # the instantiation that ran
+                            per[key] = (kv["FETCH_SIZE"] * 1024.0, kv["WRITE_SIZE"] * 1024.0)
                 if per:
-                    traffic = sum(per.values())
-                    traffic_src = ("%s (collected at git head %s; not measured in this run: counters cannot be read from inside the "
-                                   "process): FETCH_SIZE + WRITE_SIZE of the last dispatch, uncorrected — FETCH_SIZE counts half the bytes "
-                                   "of 16 B/lane streaming reads (guide), 8-12 B/lane streams and divergent gathers are uncalibrated"
-                                   % (os.path.basename(cands[-1]), pm.get("_collected_at_git_head", "unknown")))
+                    raw_fetch = sum(v[0] for v in per.values())
+                    raw_write = sum(v[1] for v in per.values())
+                    tuple_bytes = 12 if (w["bits"] > 8 and not small) else 16                              # the partitioned tuples this kernel streams
+                    stream_lines = tuple_bytes * (nR + nS)
+                    cal = None
+                    cal_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_calibration.json")))
+                    if cal_file:
+                        cal = json.load(open(cal_file[-1]))
+                    f_stream = (cal or {}).get("calib_stream_read12", {}).get("fetch_true_over_raw", 2.0)
+                    gather_raw = max(0.0, raw_fetch - stream_lines / f_stream)
+                    traffic = int(stream_lines + gather_raw + raw_write)
+                    traffic_detail = {"raw_FETCH_SIZE": int(raw_fetch), "raw_WRITE_SIZE": int(raw_write), "raw_sum": int(raw_fetch + raw_write),
+                                      "stream_lines": int(stream_lines), "stream_factor": f_stream, "gather_requests_bytes": int(gather_raw),
+                                      "corrected": traffic, "corrected_over_algorithmic": traffic / probe_bytes,
+                                      "calibration": os.path.basename(cal_file[-1]) if cal_file else None,
+                                      "pmc_file": os.path.basename(cands[-1]),
+                                      "pmc_collected_at": {"git_head": pm.get("_collected_at_git_head", "unknown"), "source_fingerprint": pm.get("_source_fingerprint", "unknown")},
+                                      "running": {"source_fingerprint": source_fingerprint()}}
+                    traffic_src = ("%s: FETCH_SIZE + WRITE_SIZE of the kernel's last dispatch (separate --pmc passes; not measured in this run: counters "
+                                   "cannot be read from inside the process), CORRECTED by %s: streaming reads count half (x2 on the %d-byte tuples "
+                                   "both relations are streamed as), gather requests and stores count as they are; raw and corrected bytes in "
+                                   "traffic_detail" % (os.path.basename(cands[-1]), os.path.basename(cal_file[-1]) if cal_file else "the guide's rule", tuple_bytes))
         except Exception:
-            traffic, traffic_src = None, None
+            traffic, traffic_src, traffic_detail = None, None, None
         res = {
             "metric": "probe throughput (10^9 tuples/s) + achieved HBM GB/s",
             "value": world * nS * args.steps / elapsed / 1e9,
@@ -676,6 +712,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": probe_kernel,
                          "achieved": gbs(probe_bytes, stage["ms_probe"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(probe_bytes, stage["ms_probe"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_detail": traffic_detail,
                          "algorithmic_bytes": probe_bytes, "ms": stage["ms_probe"],
                          "formula": "16*nS + 16*nR + 16*matches (SURVEY.md 8d)"},
             "roofline_partition": {"bound": "hbm", "kernel": "radix partition of both relations (all passes: tile-local pass, "

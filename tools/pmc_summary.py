@@ -17,6 +17,18 @@ for d in sorted(glob.glob("gpurun_out/pmc_%s_*/" % tag)):
             out[k]["ns"] = ns
 if len(sys.argv) > 2:
     out["_collected_at_git_head"] = sys.argv[2]
+sys.path.insert(0, ".")
+try:
+    import bench
+    out["_source_fingerprint"] = bench.source_fingerprint()
+except Exception:
+    pass
+# calibrated reading (profiles/r04_calibration.json, tools/micro/calib.hip): streaming reads of 8 / 12 / 16 B a lane count exactly half in
+# FETCH_SIZE, stores exactly; kernels that only stream (the partition passes, the filter) are corrected here, the join kernels —
+# streams and 64-byte gather requests in one counter — in bench.py, which knows how many tuples they stream
+for k, v in out.items():
+    if isinstance(v, dict) and "FETCH_SIZE" in v and not any(x in k for x in ("k_join", "k_probe", "k_build", "k_lr_")):
+        v["FETCH_SIZE_corrected_x2"] = v["FETCH_SIZE"] * 2.0
 json.dump(out, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1)
 for k, v in out.items():
     if not isinstance(v, dict):
