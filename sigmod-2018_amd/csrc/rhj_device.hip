@@ -580,7 +580,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         if (ensure(g.cntR, (size_t)a0.tiles * 256 * 4) || ensure(g.cntS, (size_t)a1.tiles * 256 * 4) ||
             ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
             ensure(g.status, status_words * 8 + 64) ||
-            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
+            ensure(g.ovf, fj_ovf_bytes((size_t)g.cus)) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
             ensure(g.walk, (unit_bound + 1) * sizeof(FjWalkItem)))
             return -1;
         a0.cnt = (uint32_t *)g.cntR.p; a1.cnt = (uint32_t *)g.cntS.p;
@@ -687,7 +687,7 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
         // does not fit LDS (then the tiled path below takes over).  One host sync per join.
         if (ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) ||
             ensure(g.status, (unit_bound + 1) * 8 + 64) ||
-            ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
+            ensure(g.ovf, fj_ovf_bytes((size_t)g.cus)) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
             ensure(g.walk, (unit_bound + 1) * sizeof(FjWalkItem)))
             return -1;
         FusedArgs fa;
@@ -938,7 +938,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
         ensure(g.meta, (size_t)bins * sizeof(BucketMeta)) || ensure(g.summary, sizeof(PlanSummary) + 64) ||
         ensure(g.ucount, max_units * 8) || ensure(g.ubase, max_units * 8) || ensure(g.uflag, max_units * 4) ||
         ensure(g.stash_cnt, nR + nS + 64) || ensure(g.stash_row, (nR + nS + 8) * 8) || ensure(g.status, (unit_bound + 1) * 8 + 64) ||
-        ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
+        ensure(g.ovf, fj_ovf_bytes((size_t)g.cus)) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4) ||
         ensure(g.walk, (unit_bound + 1) * sizeof(FjWalkItem)))
         return -1;
     PlanArgs pa;
@@ -1868,7 +1868,7 @@ int rhj_dev_reserve(uint64_t rows)
         ensure(g.cntR, (size_t)tiles * 256 * 4) || ensure(g.cntS, (size_t)tiles * 256 * 4) ||
         ensure(g.stash_cnt, 2 * rows + 64) || ensure(g.stash_row, (2 * rows + 8) * 8) ||
         ensure(g.status, (units + 9) * 8 + 64) || ensure(g.units, units * sizeof(Unit)) ||
-        ensure(g.ovf, (size_t)g.cus * 2 * FJ_OVF_CAP * 8) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
+        ensure(g.ovf, fj_ovf_bytes((size_t)g.cus)) || ensure(g.ovf_base, (size_t)g.cus * 2 * FJ_GROUPS * 16 * 4))
         return -1;
     return 0;
 }

@@ -36,6 +36,9 @@ constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
 constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
 constexpr uint32_t FJ_LDS_EXTRA = 2048;         // bytes of LDS behind the table (static: the words below, the speculative kernel's group prefixes)
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
+// bytes of FusedArgs::ovf for `wgs` workgroups: two overflow / record buffers each, and behind them all a piece of 256 16-byte
+// records per wave (fj_walk_group's staging)
+constexpr size_t fj_ovf_bytes(size_t wgs) { return wgs * 2 * (size_t)32768 * 8 + wgs * (size_t)(1024 / 64) * 256 * 16; }
 constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
 #ifndef FJ_WIN
 #define FJ_WIN 8                                // entries of a slot compared at once (the array is padded by 8)
@@ -962,16 +965,17 @@ __device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, con
 // found in slot order = descending build position (rhjoin.c:219-250), so the ordinal is the number found before.  Then the
 // group's total goes into the chained scan of the unit's groups (fj_group_lookback), the first matches leave from the
 // registers and the records are read back 64 at a time, each pair to its tuple's offset + ordinal.  Returns the lane's matches.
-constexpr uint32_t FJ_REC_CAP = 256;                  // records (second and later matches) of one group; more: the speculation is off
+constexpr uint32_t FJ_REC_CAP = 256;                  // records (second and later matches) of one group; more: the speculation is off / the unit is walked
+// The candidate walk of one group: c = matches per tuple, first = the first match's build row id, the records of the others in
+// rec[0 .. returned count) (at most FJ_REC_CAP are stored; `cannot`: more than that, or an ordinal beyond eight bits).
 template <bool N32, class IX>
-__device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<N32> &G, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
-                                                    bool flip, uint32_t grp, uint32_t *gpre, uint64_t spec_base, uint4 *rec,
-                                                    uint4 *out, uint64_t cap, bool &cannot)
+__device__ __forceinline__ uint32_t fj_walk_group(const IX &X, const FjGather<N32> &G, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
+                                                  uint4 *rec, uint32_t (&c)[FJ_V], uint32_t (&first)[FJ_V], bool &cannot)
 {
     constexpr int V = FJ_V;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt = lanemask_lt();
-    uint32_t sn[V], tm[V], c[V], first[V];
+    uint32_t sn[V], tm[V];
     // (The lane-by-lane loop below picks one of the lane's four tuples by a run-time index.  hipcc turns a select between
     // loads of the caller's array into a load through a selected POINTER — and the array into 64 bytes of scratch per lane;
     // values that come out of an (empty) asm statement are not loads any more.)
@@ -1057,6 +1061,38 @@ __device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<
         }
     }
     cannot = cannot || ne > FJ_REC_CAP;
+    return min(ne, FJ_REC_CAP);
+}
+
+// the records of a group, read back 64 at a time: each pair to its tuple's offset (off[k] of the lane that holds the tuple) + ordinal
+__device__ __forceinline__ void fj_emit_records(bool flip, const uint4 *rec, uint32_t nrec, const uint32_t (&off)[FJ_V], uint64_t wbase,
+                                                uint4 *out, uint64_t cap)
+{
+    constexpr int V = FJ_V;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
+        const uint32_t e = e0 + lane;
+        const uint4 r = e < nrec ? rec[e] : make_uint4(0, 0, 0, 0);
+        const int src = (int)(r.z & 63u);
+        const uint32_t kk = (r.z >> 6) & 3u;
+        uint32_t o = __shfl(off[0], src, 64);
+#pragma unroll
+        for (int k = 1; k < V; ++k) { const uint32_t ok_ = __shfl(off[k], src, 64); if (kk == (uint32_t)k) o = ok_; }
+        const uint64_t at = wbase + o + (r.z >> 8);
+        if (e < nrec && at < cap) out[at] = make_pair(flip, r.y, 0u, r.x, 0u);
+    }
+}
+
+// SPEC, the other relation probes: the group's pairs leave at once (see above).  Returns the lane's matches.
+template <bool N32, class IX>
+__device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<N32> &G, const uint4 (&q)[FJ_V], const bool (&okk)[FJ_V],
+                                                    bool flip, uint32_t grp, uint32_t *gpre, uint64_t spec_base, uint4 *rec,
+                                                    uint4 *out, uint64_t cap, bool &cannot)
+{
+    constexpr int V = FJ_V;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t c[V], first[V];
+    const uint32_t nrec = fj_walk_group<N32>(X, G, q, okk, rec, c, first, cannot);
     uint32_t off[V], wrun = 0, cs = 0;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -1075,18 +1111,7 @@ __device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<
         const uint64_t at = wbase + off[k];
         if (c[k] != 0 && at < cap) out[at] = make_pair(flip, q[k].z, 0u, first[k], 0u);
     }
-    const uint32_t nrec = min(ne, FJ_REC_CAP);
-    for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
-        const uint32_t e = e0 + lane;
-        const uint4 r = e < nrec ? rec[e] : make_uint4(0, 0, 0, 0);
-        const int src = (int)(r.z & 63u);
-        const uint32_t kk = (r.z >> 6) & 3u;
-        uint32_t o = __shfl(off[0], src, 64);
-#pragma unroll
-        for (int k = 1; k < V; ++k) { const uint32_t ok_ = __shfl(off[k], src, 64); if (kk == (uint32_t)k) o = ok_; }
-        const uint64_t at = wbase + o + (r.z >> 8);
-        if (e < nrec && at < cap) out[at] = make_pair(flip, r.y, 0u, r.x, 0u);
-    }
+    fj_emit_records(flip, rec, nrec, off, wbase, out, cap);
     return cs;
 }
 
@@ -1133,6 +1158,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     uint4 *out = reinterpret_cast<uint4 *>(a.out);
     const bool emitting = out != nullptr && FJ_ABLATE != 3;
     if ((a.summary->wide_row_ids == 0) != N32) return;                 // the other instantiation's launch does the join
+    uint4 *stg = reinterpret_cast<uint4 *>(f.ovf + (size_t)gridDim.x * 2 * FJ_OVF_CAP) + ((size_t)blockIdx.x * FJ_WAVES + w) * FJ_REC_CAP;   // this wave's piece
     uint32_t pend = 0xffffffffu;                      // unit whose emit pass is deferred
     uint64_t pend_total = 0;
     bool pend_dup = false;
@@ -1233,9 +1259,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
             // SPEC, the OTHER relation probes a gathered build side: the unit's first pair is known (the hypothesis' relation's
             // psum), so all a group needs is the match total of the groups in front of it — a chained scan among the waves of
             // this workgroup, in LDS — and its pairs go out from here (fj_group_direct): no stash, no emit pass.
-            mine += fj_group_direct<N32>(X, G, q, okk, flip, grp, gpre, spec_base,
-                                         reinterpret_cast<uint4 *>(f.ovf + (size_t)blockIdx.x * 2 * FJ_OVF_CAP) + w * FJ_REC_CAP,
-                                         out, a.out_capacity, needs_index);
+            mine += fj_group_direct<N32>(X, G, q, okk, flip, grp, gpre, spec_base, stg, out, a.out_capacity, needs_index);
             continue;
         }
         if (RES) fj_count_res(X, ltup, q, okk, c, flo, fhi, fp, run);
