@@ -36,9 +36,10 @@ constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
 constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
 constexpr uint32_t FJ_LDS_EXTRA = 2048;         // bytes of LDS behind the table (static: the words below, the speculative kernel's group prefixes)
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
-// bytes of FusedArgs::ovf for `wgs` workgroups: two overflow / record buffers each, and behind them all a piece of 256 16-byte
-// records per wave (fj_walk_group's staging)
-constexpr size_t fj_ovf_bytes(size_t wgs) { return wgs * 2 * (size_t)32768 * 8 + wgs * (size_t)(1024 / 64) * 256 * 16; }
+constexpr uint32_t FJ_REC_CAP = 512;                  // 16-byte records (second and later matches) of one 256-tuple group: two a tuple on average; more: the speculation is off
+// bytes of FusedArgs::ovf for `wgs` workgroups: two overflow buffers each, and behind them all a piece of FJ_REC_CAP records per wave
+// (fj_walk_group's staging)
+constexpr size_t fj_ovf_bytes(size_t wgs) { return wgs * 2 * (size_t)32768 * 8 + wgs * (size_t)(1024 / 64) * FJ_REC_CAP * 16; }
 constexpr uint32_t FJ_OVF_J = 15;               // match ordinals 1..15 (2nd..16th match) have an overflow slot
 #ifndef FJ_WIN
 #define FJ_WIN 8                                // entries of a slot compared at once (the array is padded by 8)
@@ -965,7 +966,6 @@ __device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, con
 // found in slot order = descending build position (rhjoin.c:219-250), so the ordinal is the number found before.  Then the
 // group's total goes into the chained scan of the unit's groups (fj_group_lookback), the first matches leave from the
 // registers and the records are read back 64 at a time, each pair to its tuple's offset + ordinal.  Returns the lane's matches.
-constexpr uint32_t FJ_REC_CAP = 256;                  // records (second and later matches) of one group; more: the speculation is off / the unit is walked
 // The candidate walk of one group: c = matches per tuple, first = the first match's build row id, the records of the others in
 // rec[0 .. returned count) (at most FJ_REC_CAP are stored; `cannot`: more than that, or an ordinal beyond eight bits).
 template <bool N32, class IX>

@@ -206,6 +206,45 @@ def test_foreign_key_speculation_holds_or_hands_over(rhj, oracle):
         rhj.lib.rhj_set_spec(1)
 
 
+def test_speculation_on_gathered_build_sides_both_kinds_of_units(rhj, oracle):
+    """k_join_spec<false> — build sides beyond the LDS-resident size (7.8 K tuples a bucket: 8M x 8M at 10 bits), both relations
+    the same size, so that about half of the buckets are probed by S, the hypothesis' relation (pairs written from the probe loop)
+    and half by R (fj_group_direct: first candidates four a lane, the others lane by lane, second and later matches as records,
+    the groups of a unit chained in LDS).  Uniform draws (0..9 matches an R tuple); draws from half of R's keys (twice the
+    matches, ~145 records a group); from an eighth (eight matches a key, ~224 records a group); from the FIRST quarter of R's
+    tuples (whole groups of tuples with four matches each: more than the 512 records a wave keeps: handed over); one R tuple with
+    300 matches (the ordinal has eight bits: handed over).  The pairs are the oracle's in every case."""
+    bits, n = 10, 8_000_000
+    rhj.set_bits(bits)
+    set_path(rhj, "fused")
+    R = oracle.generate(n, 0, 0, 0.0, 191)
+    rng = np.random.default_rng(192)
+    def run(S, expect):
+        rhj.lib.rhj_set_spec(1)
+        want = oracle.join(R, S, bits)
+        t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), capacity=len(S) + 16)
+        got = rhj.pairs_to_numpy(t)[:m]
+        assert m == len(want) and (got == want).all()
+        assert rhj.lib.rhj_last_spec() == expect, (rhj.lib.rhj_last_spec(), expect)
+    try:
+        S = helpers.make_rel(R["value"][rng.integers(0, n, n)])
+        run(S, 1)
+        some = rng.permutation(n)                                    # (a random half / eighth of R's tuples: mixed with the others inside every group)
+        run(helpers.make_rel(R["value"][some[rng.integers(0, n // 2, n)]]), 1)
+        run(helpers.make_rel(R["value"][some[rng.integers(0, n // 8, n)]]), 1)
+        run(helpers.make_rel(R["value"][rng.integers(0, n // 4, n)]), 2)     # the FIRST quarter of R's tuples: whole groups of them in every bucket
+        S3 = S.copy()
+        hr = np.bincount((R["value"] & np.uint64(1023)).astype(np.int64), minlength=1024)
+        hs = np.bincount((S3["value"] & np.uint64(1023)).astype(np.int64), minlength=1024)
+        b0 = int(np.nonzero(hr >= hs)[0][0])                         # a bucket R probes (rhjoin.c:86)
+        k0 = R["value"][np.nonzero((R["value"] & np.uint64(1023)) == np.uint64(b0))[0][7]]
+        same_bucket = np.nonzero((S3["value"] & np.uint64(1023)) == np.uint64(b0))[0]
+        S3["value"][same_bucket[:300]] = k0                          # (the bucket's sizes stay what they were)
+        run(S3, 2)
+    finally:
+        rhj.lib.rhj_set_spec(1)
+
+
 def test_row_id_width_is_speculated_and_a_wrong_guess_runs_again():
     """The 16-byte kernels of the two-pass partition are not launched until a join of the process has needed them: the first
     join with wide row ids is reported as an overflow by the sample and run again wide; later joins launch both widths."""
