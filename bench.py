@@ -13,7 +13,8 @@ finaliser so all 64 bits are populated):
     c3    100M x 100M uniform FK, 12 radix bits     (BASELINE configs[2]; default: the
           configuration the HBM-roofline target is stated on — c2's 48 MB working set
           lives in the Infinity Cache, so an HBM fraction is meaningless there)
-    c4    100M x 1B  Zipf(0.9),   12 radix bits     (BASELINE configs[3])
+    c4    100M x 1B  Zipf(0.9),   14 radix bits     (BASELINE configs[3]; the config leaves the
+          radix free: at 14 bits a bucket's 6.1 K build tuples are LDS-resident)
 N > 1: every rank joins its own independent relations of the same size (weak scaling:
 independent joins of a plan shard across GPUs with no data-path collective).
 """
