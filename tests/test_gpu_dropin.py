@@ -20,9 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENGINES = {name: os.path.join(ROOT, "oracle", "_ref", name) for name in ("radixhash_rhj", "radixhash_rhj_resident")}
 
 
-@pytest.mark.parametrize("engine", sorted(ENGINES))
+@pytest.mark.parametrize("engine,devices", [(e, 0) for e in sorted(ENGINES)] + [("radixhash_rhj", 1), ("radixhash_rhj", 3)])
 @pytest.mark.parametrize("empty_mode", ["head", "null"])
-def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode, engine):
+def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode, engine, devices):
+    """devices > 0: the same unchanged engine with RHJ_DEVICES set — every RadixHashJoin() of the 50 queries sharded by bucket
+    range over that many device contexts inside the one process (include/rhj.h; RHJ_DEVICES_SAME=1: all of them on the box's
+    one GPU), every device's pairs moved to their place in the one result list: the golden file again, line by line."""
     ENGINE = ENGINES[engine]
     if not os.path.exists(ENGINE):
         pytest.skip("oracle/_ref/%s not built (needs /root/reference at build time)" % engine)
@@ -37,6 +40,8 @@ def test_reference_engine_on_small_workload(golden, tmp_path, empty_mode, engine
         names.append("r%d" % i)
     stdin = "\n".join(names) + "\nDone\n" + "\n".join(golden.small["work_lines"]) + "\n"
     env = dict(os.environ, RHJ_EMPTY=empty_mode, RHJ_RADIX_BITS="4")
+    if devices:
+        env.update(RHJ_DEVICES=str(devices), RHJ_DEVICES_SAME="1")
     res = subprocess.run([ENGINE], input=stdin.encode(), cwd=str(tmp_path), env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
