@@ -202,6 +202,11 @@ int  rhj_last_exact(void);
 int  rhj_set_devices(int n);
 int  rhj_get_devices(void);
 int  rhj_device_range(int bits, int n, int d, uint32_t *lo, uint32_t *hi);
+/* rhj_set_devices_balance(1) / env RHJ_DEVICES_BALANCE=hist: rhj_join_devices cuts the ranges by histR + histS (two histogram
+ * launches on the library's device and one read-back) instead of equal widths — for skewed keys; rhj_plan_device_ranges() is
+ * that plan (cuts[d] .. cuts[d + 1] = device d's buckets; needs no GPU).  Ranges are cut BETWEEN buckets. */
+void rhj_set_devices_balance(int by_histogram);
+int  rhj_plan_device_ranges(const uint64_t *histR, const uint64_t *histS, int bits, int n, uint32_t *cuts);
 int  rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *const *d_S, uint64_t nS,
                       rhj_result_tuple *const *out, const uint64_t *capacity, uint64_t *matches);
 int  rhj_gather_pairs_devices(const rhj_result_tuple *const *lists, const uint64_t *matches, int dst_device,

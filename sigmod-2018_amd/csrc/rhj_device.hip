@@ -131,6 +131,7 @@ thread_local Ctx *g_cur = &g_all[0];
 #define g (*g_cur)
 int g_ndev = 1;                      // devices a join is sharded over (rhj_set_devices, env RHJ_DEVICES)
 int g_ndev_env = 0;                  // RHJ_DEVICES as read at load time (applied by the first call that can shard)
+int g_balance = 0;                   // 1: rhj_join_devices cuts the bucket ranges by histR + histS instead of equal widths (rhj_set_devices_balance, env RHJ_DEVICES_BALANCE=hist)
 int g_same_device = 0;               // RHJ_DEVICES_SAME=1 (tests): every context on the library's own device — n streams and workspaces on one GPU
 
 // environment defaults are read once at load time; the rhj_set_* calls override them
@@ -141,6 +142,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_DEVICE"))) g.device = atoi(e);
         if ((e = getenv("RHJ_DEVICES"))) g_ndev_env = atoi(e);
         if ((e = getenv("RHJ_DEVICES_SAME"))) g_same_device = atoi(e);
+        if ((e = getenv("RHJ_DEVICES_BALANCE"))) g_balance = strcmp(e, "hist") == 0;
         if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 15) g.bits = b; }
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
@@ -1383,6 +1385,27 @@ int rhj_join_device_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_
 }
 
 int rhj_set_devices(int n) { RhjApiLock api_lock; g_ndev_env = 0; return set_devices(n); }
+/* Contiguous bucket ranges for n devices balanced by histR + histS (skewed keys): cuts[d] .. cuts[d + 1] is device d's range.
+ * shard.bucket_ranges in C: the first bucket at which the running total reaches d / n of all tuples; no device needed. */
+int rhj_plan_device_ranges(const uint64_t *histR, const uint64_t *histS, int bits, int n, uint32_t *cuts)
+{
+    if (bits < 1 || bits > MAX_BITS || n < 1 || n > MAX_DEVICES) return -1;
+    const uint32_t bins = 1u << bits;
+    double total = 0.0;
+    for (uint32_t b = 0; b < bins; ++b) total += (double)histR[b] + (double)histS[b];
+    cuts[0] = 0;
+    uint32_t at = 0;
+    double cum = 0.0;                                  // tuples in front of bucket `at`
+    for (int d = 1; d < n; ++d) {
+        const double target = total * (double)d / (double)n;
+        while (at < bins && cum < target) { cum += (double)histR[at] + (double)histS[at]; ++at; }
+        cuts[d] = at;
+    }
+    cuts[n] = bins;
+    return 0;
+}
+void rhj_set_devices_balance(int by_histogram) { RhjApiLock api_lock; g_balance = by_histogram != 0; }
+
 /* the bucket range device d of n joins at `bits` radix bits (no device needed: the planning half of rhj_join_devices) */
 int rhj_device_range(int bits, int n, int d, uint32_t *lo, uint32_t *hi)
 {
@@ -1404,12 +1427,24 @@ int rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *
     RhjApiLock api_lock;
     if (devices_ready()) return -1;
     const int n = g_ndev;
-    const uint32_t bins = 1u << g_all[0].bits;
+    const int bits = g_all[0].bits;
+    const uint32_t bins = 1u << bits;
+    uint32_t cuts[MAX_DEVICES + 1];
+    for (int d = 0; d <= n; ++d) cuts[d] = range_cut(bins, n, d);
+    if (g_balance && n > 1 && nR && nS) {
+        // skewed keys: the library's own device counts both relations' buckets (two launches, one read-back of 2^bits words each)
+        if (ctx_init() || ensure(g.passhp, (size_t)2 * bins * 8)) return -1;
+        uint64_t *d_h = (uint64_t *)g.passhp.p;
+        std::vector<uint64_t> h((size_t)2 * bins);
+        if (rhj_bucket_histogram_device(d_R[0], nR, d_h) || rhj_bucket_histogram_device(d_S[0], nS, d_h + bins)) return -1;
+        HIP_TRY(hipMemcpyAsync(h.data(), d_h, (size_t)2 * bins * 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (rhj_plan_device_ranges(h.data(), h.data() + bins, bits, n, cuts)) return -1;
+    }
     int rcs[MAX_DEVICES] = {0};
     try {
         on_devices(n, [&](int d) {
-            rcs[d] = join_range(d_R[d], nR, d_S[d], nS, range_cut(bins, n, d), range_cut(bins, n, d + 1), out[d], capacity[d], false,
-                                nullptr, &matches[d]);
+            rcs[d] = join_range(d_R[d], nR, d_S[d], nS, cuts[d], cuts[d + 1], out[d], capacity[d], false, nullptr, &matches[d]);
         });
     } catch (...) { return -1; }
     int rc = 0;

@@ -83,6 +83,20 @@ for bits in (4, 8, 11):
     assert lib.rhj_gather_pairs_devices(po, ms, n - 1, full.data_ptr(), len(want), C.byref(tot)) == 0 and tot.value == len(want)
     assert (rhj.pairs_to_numpy(full) == want).all()
     assert lib.rhj_gather_pairs_devices(po, ms, n - 1, full.data_ptr(), len(want) - 1, C.byref(tot)) == 1
+    # (4) ranges balanced by histR + histS (skewed S): same result, every list inside the planned range
+    lib.rhj_set_devices_balance(1)
+    assert lib.rhj_join_devices(pr, len(R), ps, len(S), po, caps, ms) == 0
+    parts = [rhj.pairs_to_numpy(t)[:int(m)] for t, m in zip(outs, ms)]
+    assert (np.concatenate(parts) == want).all(), ("balanced", bits)
+    mask = np.uint64((1 << bits) - 1)
+    hr = np.bincount((R["value"] & mask).astype(np.int64), minlength=1 << bits).astype(np.uint64)
+    hs = np.bincount((S["value"] & mask).astype(np.int64), minlength=1 << bits).astype(np.uint64)
+    cuts = (C.c_uint32 * (n + 1))()
+    assert lib.rhj_plan_device_ranges(hr.ctypes.data_as(C.POINTER(C.c_uint64)), hs.ctypes.data_as(C.POINTER(C.c_uint64)), bits, n, cuts) == 0
+    for d, part in enumerate(parts):
+        b = np.array([keyR[int(x)] for x in part["row_idR"][:3000]], dtype=np.uint64) & mask
+        assert ((b >= cuts[d]) & (b < cuts[d + 1])).all()
+    lib.rhj_set_devices_balance(0)
     # a list that does not fit its device's buffer: the count comes back, rc 1
     caps2 = (C.c_uint64 * n)(*[10] * n)
     assert lib.rhj_join_devices(pr, len(R), ps, len(S), po, caps2, ms) == 1 and sum(int(m) for m in ms) == len(want)

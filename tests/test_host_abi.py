@@ -102,6 +102,17 @@ def test_device_ranges_are_the_sharding_modules_equal_ranges(lib):
                 got.append((lo.value, hi.value))
             assert got == shard.equal_ranges(bits, n), (bits, n)
             assert got[0][0] == 0 and got[-1][1] == 1 << bits and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    # the histogram-balanced plan against shard.bucket_ranges: uniform, Zipf-like, one hot bucket, empty buckets, all in one
+    rng = np.random.default_rng(7)
+    for bits in (1, 4, 8, 12):
+        bins = 1 << bits
+        for hist in (rng.integers(0, 1000, (2, bins)), (rng.zipf(1.3, (2, bins)) % 100000), np.zeros((2, bins), dtype=np.int64),
+                     np.vstack([np.eye(1, bins, bins // 3, dtype=np.int64)[0] * 10**9 + 3, np.ones(bins, dtype=np.int64)])):
+            hr, hs = (np.ascontiguousarray(h, dtype=np.uint64) for h in hist)
+            for n in range(1, 9):
+                cuts = (C.c_uint32 * (n + 1))()
+                assert lib.rhj_plan_device_ranges(hr.ctypes.data_as(C.POINTER(C.c_uint64)), hs.ctypes.data_as(C.POINTER(C.c_uint64)), bits, n, cuts) == 0
+                assert [(cuts[d], cuts[d + 1]) for d in range(n)] == [(int(a), int(b)) for a, b in shard.bucket_ranges(hr, hs, n)], (bits, n)
     assert lib.rhj_device_range(4, 9, 0, C.byref(lo), C.byref(hi)) == -1       # at most eight devices
     assert lib.rhj_device_range(4, 2, 2, C.byref(lo), C.byref(hi)) == -1
     assert lib.rhj_device_range(16, 2, 0, C.byref(lo), C.byref(hi)) == -1
