@@ -24,4 +24,10 @@ cp gpurun_out/pmc_${tag}.json gpurun_out/${tag}_c3_pmc.json
 python3 tools/filter_bench.py > gpurun_out/${tag}_filter.json 2>/dev/null || echo "filter bench failed"
 python3 tools/host_rate.py > gpurun_out/${tag}_host_rate.json 2>/dev/null || echo "host rate failed"
 python3 tools/small_e2e.py > gpurun_out/${tag}_small_e2e.json 2>/dev/null || echo "small e2e failed"
+
+# SQ counters of the C3 kernels (three passes; per launch, summed over the chip)
+bash tools/pmc.sh ${tag}sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" -- --steps 3 --warmup 2 --no-cpu-baseline || echo "sq passes failed"
+python3 tools/pmc_summary.py ${tag}sq $head > /dev/null && cp gpurun_out/pmc_${tag}sq.json gpurun_out/${tag}_c3_pmc_sq.json
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_c3_bench_after_pmc.json 2>/dev/null
+echo "sq done"
 echo "all done"
