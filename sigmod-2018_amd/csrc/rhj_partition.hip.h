@@ -35,6 +35,23 @@ __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok, int bits)
 
 // Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
 // (RANGED: a sharded join — tuples of another rank's buckets are not counted; compiled apart, see k_local_part)
+// Exclusive scan of the values held by the first `items` threads (items <= 4 * 64; the others pass 0) with ONE barrier: every wave
+// scans its 64 values, leaves its total in `sm4` and adds the totals of the waves in front of it — where the workgroup scan of
+// rhj_common.hip.h takes three barriers (a batch of pass 2 has two such scans at more than 64 digits / runs: 100M x 1B at 14 bits,
+// the low-radix path's 256 digits; in pass 1, one scan a tile, the same change measured +4 % on 100M x 1B and is not there).  `sm4`: four words nobody else touches until the caller's next barrier.  Returns the thread's
+// exclusive prefix, *total = the sum (valid in every thread).
+__device__ __forceinline__ uint32_t scan_upto_256(uint32_t v, uint32_t *total, uint32_t *sm4)
+{
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t x = wave_incl_scan_u32(v);
+    if (lane == 63 && w < 4) sm4[w] = x;
+    __syncthreads();
+    const uint32_t t0 = sm4[0], t1 = sm4[1], t2 = sm4[2], t3 = sm4[3];
+    *total = t0 + t1 + t2 + t3;
+    const uint32_t carry = (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+    return carry + x - v;
+}
+
 template <bool RANGED>
 __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits)
 {
@@ -811,12 +828,12 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
             if (threadIdx.x < bins) gbase[threadIdx.x] = gb;
             return 0u;
         }
-        uint64_t tot64;
-        const uint32_t off = (uint32_t)block_excl_scan<PT_BLOCK>(len, &tot64, sm);
-        if (threadIdx.x < SR_RUNOFF) runoff[threadIdx.x] = threadIdx.x < r.group ? off : (uint32_t)tot64;
+        uint32_t tot;                                 // (at most PT_MAX_GROUP = 256 runs: thread i holds run i's length, the others 0)
+        const uint32_t off = scan_upto_256(len, &tot, reinterpret_cast<uint32_t *>(sm));
+        if (threadIdx.x < SR_RUNOFF) runoff[threadIdx.x] = threadIdx.x < r.group ? off : tot;
         if (threadIdx.x < PT_MAX_GROUP) rbase[threadIdx.x] = phys - off;
         if (threadIdx.x < bins) gbase[threadIdx.x] = gb;
-        return (uint32_t)tot64;
+        return tot;
     };
     uint32_t tk[SR_V], th[SR_V], tr[SR_V], tw[SR_V];  // the batch's tuples (tw: upper row-id word of 16-byte tuples)
     // run search + loads of batch [sb, sb + count) of the tile whose run table is in buffer `buf`
@@ -917,8 +934,10 @@ __global__ __launch_bounds__(PT_BLOCK, SR_MINW) void k_scatter_runs(RelArgs r0, 
         if (bins <= (uint32_t)WAVE) {                 // the digits are wave 0's lanes: a wave scan, no workgroup scan (workgroup-uniform)
             uint32_t unused;
             ds = w == 0 ? wave_excl_scan_u32((uint32_t)mytotal, &unused) : 0u;
-        } else
-            ds = block_excl_scan<PT_BLOCK>(mytotal, nullptr, sm);
+        } else {                                      // at most 256 digits
+            uint32_t unused;
+            ds = scan_upto_256((uint32_t)mytotal, &unused, reinterpret_cast<uint32_t *>(sm) + 4);
+        }
         if (threadIdx.x < bins) {
             dstart[threadIdx.x] = (uint32_t)ds;
             const uint32_t gb = gbase[threadIdx.x];
