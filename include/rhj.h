@@ -217,7 +217,7 @@ int  rhj_gather_pairs_devices(const rhj_result_tuple *const *lists, const uint64
  * width the library picks from the relation sizes (rhj_get_stats().radix_bits says which): for callers whose
  * answers do not depend on the order — the reference's query executor is one: its view sums are order-free
  * (inter_res.c:320-339), tests/test_gpu_dropin.py runs it this way — and who therefore need not run big joins on
- * buckets sized for a CPU cache (100M x 100M: 23.5 ms on 4 bits, 5.2 ms on the library's 13).
+ * buckets sized for a CPU cache (100M x 100M on the reference's 4 bits: 7.1 ms in its canonical order, 4.1 ms on the 12 bits the library picks).
  * rhj_partition_device() always uses the radix width in force. */
 void rhj_set_order(int any);
 int  rhj_get_order(void);

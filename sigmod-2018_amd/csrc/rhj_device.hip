@@ -1062,6 +1062,10 @@ static int auto_radix_bits(uint64_t nR, uint64_t nS)
     int b = 0;
     while (b < MAX_BITS && (nmin >> b) > target) ++b;
     while (b < PT_MAX_BITS && (nmin >> (b + 1)) >= 512) ++b;
+    // 13 bits only where 12 would leave buckets beyond the gather kernels' LDS index: up to 12 bits pass 1 counts pass 2's digits
+    // itself, and since the speculative kernel writes every unit's pairs from phase 1 (round 4) 100M x 100M is faster on 12 bits
+    // (24.4 K a bucket: 4.13 ms) than on 13 (4.27) or 14 (4.54); tools/exp_auto_bits.py: 10M / 30M / 50M best on 10 / 11 / 12
+    if (b == 13 && nmax < 4 * nmin && (nmin >> 12) <= 28000) b = 12;
     return b < 1 ? 1 : b;
 }
 

@@ -65,9 +65,9 @@ def test_any_order_is_the_canonical_order_of_the_chosen_radix(rhj, oracle, nR, n
 
 
 def test_any_order_radix_choice(rhj):
-    """100M x 100M would take 13 bits, 100M x 1B 14 (sizes only: nothing is allocated here)."""
+    """100M x 100M would take 12 bits, 100M x 1B 14 (sizes only: nothing is allocated here)."""
     rule = rhj.lib.rhj_auto_radix_bits
-    assert rule(100_000_000, 100_000_000) == 13 and rule(100_000_000, 1_000_000_000) == 14 and rule(1_000_000, 1_000_000) == 8
+    assert rule(100_000_000, 100_000_000) == 12 and rule(100_000_000, 1_000_000_000) == 14 and rule(1_000_000, 1_000_000) == 8
     rng = np.random.default_rng(3)
     R = make_rel(rng.integers(0, 1 << 40, size=300_000, dtype=np.uint64))
     S = make_rel(rng.integers(0, 1 << 40, size=2_000_000, dtype=np.uint64))

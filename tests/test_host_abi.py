@@ -120,7 +120,7 @@ def test_device_ranges_are_the_sharding_modules_equal_ranges(lib):
 
 def test_order_mode_and_its_radix_rule(lib):
     """rhj_set_order / rhj_get_order and the width order mode "any" picks (include/rhj.h): build sides of ~16 K tuples per
-    bucket on comparable sizes, ~6.5 K when the probe side is four times the build side or more, and for small relations
+    bucket on comparable sizes (12 bits instead of 13 while a bucket stays below 28 K), ~6.5 K when the probe side is four times the build side or more, and for small relations
     up to 8 bits while an average bucket keeps 512 tuples.  Pure host logic: no device is touched."""
     assert lib.rhj_get_order() == 0
     lib.rhj_set_order(1)
@@ -128,7 +128,7 @@ def test_order_mode_and_its_radix_rule(lib):
     lib.rhj_set_order(0)
     assert lib.rhj_get_order() == 0
     rule = lib.rhj_auto_radix_bits
-    assert rule(100_000_000, 100_000_000) == 13
+    assert rule(100_000_000, 100_000_000) == 12
     assert rule(100_000_000, 1_000_000_000) == 14 and rule(1_000_000_000, 100_000_000) == 14
     assert rule(1_000_000, 1_000_000) == 8 and rule(100_000, 100_000) == 7
     assert rule(1, 1) == 1 and rule(1000, 5) == 1
