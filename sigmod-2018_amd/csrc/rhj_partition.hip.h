@@ -33,8 +33,6 @@ __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok, int bits)
     return ((uint64_t)phi << 32) | plo;
 }
 
-// Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
-// (RANGED: a sharded join — tuples of another rank's buckets are not counted; compiled apart, see k_local_part)
 // Exclusive scan of the values held by the first `items` threads (items <= 4 * 64; the others pass 0) with ONE barrier: every wave
 // scans its 64 values, leaves its total in `sm4` and adds the totals of the waves in front of it — where the workgroup scan of
 // rhj_common.hip.h takes three barriers (a batch of pass 2 has two such scans at more than 64 digits / runs: 100M x 1B at 14 bits,
@@ -52,6 +50,8 @@ __device__ __forceinline__ uint32_t scan_upto_256(uint32_t v, uint32_t *total, u
     return carry + x - v;
 }
 
+// Per-tile digit histogram of the one-pass partition: cnt[tile][digit] for digit = (key >> shift) & mask.
+// (RANGED: a sharded join — tuples of another rank's buckets are not counted; compiled apart, see k_local_part)
 template <bool RANGED>
 __global__ __launch_bounds__(256) void k_hist_tiles(RelArgs r0, RelArgs r1, int shift, int bits)
 {
