@@ -43,6 +43,6 @@ for it in range(iters):
         print("MISMATCH", info, "first at", bad[:5], got[bad[:3]], want[bad[:3]])
         sys.exit(1)
     print("ok", info, flush=True)
-    if how == 0 and ex == 2:
+    if how == 0 and ex == 2 and (nbig > nsmall or R is uniq):      # (equal sizes: the hypothesis is on S — an S of unique keys breaks it by itself)
         print("an exact foreign-key join was handed over", info); sys.exit(1)
 print("stress ok: %d joins, %.0f s; k_join_exact not launched %d, did the join %d, handed over %d" % (iters, time.time() - t0, went[0], went[1], went[2]))
