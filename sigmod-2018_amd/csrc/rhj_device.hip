@@ -1267,7 +1267,7 @@ template <class F> static void on_devices(int n, F fn)
         pool.emplace_back([d, &fn]() {
             g_cur = &g_all[d];
             if (d) adopt_knobs(g_all[d], g_all[0]);
-            fn(d);
+            try { fn(d); } catch (...) { }             // (nothing may leave a thread; fn records its own result, preset to failure)
         });
     for (auto &t : pool) t.join();
 }
@@ -1445,7 +1445,8 @@ int rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *
         HIP_TRY(hipStreamSynchronize(g.stream));
         if (rhj_plan_device_ranges(h.data(), h.data() + bins, bits, n, cuts)) return -1;
     }
-    int rcs[MAX_DEVICES] = {0};
+    int rcs[MAX_DEVICES];
+    for (int d = 0; d < MAX_DEVICES; ++d) rcs[d] = -1;
     try {
         on_devices(n, [&](int d) {
             rcs[d] = join_range(d_R[d], nR, d_S[d], nS, cuts[d], cuts[d + 1], out[d], capacity[d], false, nullptr, &matches[d]);
@@ -1694,6 +1695,7 @@ int rhj_host_join(const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t 
     if (nthreads > 8) nthreads = 8;
     nthreads = nthreads / (unsigned)n ? nthreads / (unsigned)n : 1u;      // the devices' movers share the host's cores
     try {
+        for (int d = 0; d < n; ++d) rcs[d] = -1;
         on_devices(n, [&](int d) { rcs[d] = pairs_to_nodes(d_outs[d], base[d], Ms[d], node_pairs, nodes.data(), nthreads); });
     } catch (...) { return -1; }
     for (int d = 0; d < n; ++d) if (rcs[d]) return -1;
