@@ -173,11 +173,13 @@ void rhj_set_count_in_pass1(int on);
  * identical either way (env RHJ_NO_SPEC=1).  rhj_last_spec(): the last join — 0 not tried, 1 held, 2 failed. */
 void rhj_set_spec(int on);
 int  rhj_last_spec(void);
-/* 1 (default): where the speculation is tried on build sides that are not LDS-resident (radix widths of 10 bits and more,
- * 12-byte tuples), k_join_exact (csrc/rhj_join_exact.hip.h) runs it: its LDS index holds 40 bits of a bijective hash of the
- * key bits a bucket's keys differ in and is exact by itself — no gather of the build tuple, only of its row id.  It takes
- * build sides whose row ids increase with the input position (the reference's always do: inter_res.c:202,225) and hands
- * everything else to the ordinary kernels in the same call.  Results are identical either way (env RHJ_NO_EXACT=1).
+/* 0 (default) / 1 (env RHJ_EXACT=1): where the speculation is tried on build sides that are not LDS-resident (radix widths of
+ * 10 bits and more, 12-byte tuples), k_join_exact (csrc/rhj_join_exact.hip.h) runs it instead of k_join_spec: its LDS index holds
+ * 40 bits of a bijective hash of the key bits a bucket's keys differ in and is exact by itself — no gather of the build tuple,
+ * only of its row id, from an L2-resident scratch array.  It takes build sides whose row ids increase with the input position
+ * (the reference's always do: inter_res.c:202,225) and hands everything else to the ordinary kernels in the same call.
+ * Results are identical either way.  Off by default because it measured slower than the gather kernel (DESIGN.md 4.2,
+ * profiles/README.md r04a); kept as the measured alternative, with its tests.
  * rhj_last_exact(): the last join — 0 not launched, 1 it did the join, 2 it handed over. */
 void rhj_set_exact(int on);
 int  rhj_last_exact(void);
