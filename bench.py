@@ -489,6 +489,9 @@ def main():
                     help="N > 1: weak = one independent join per rank (default); strong = ONE join sharded by bucket range "
                          "over the ranks (sigmod-2018_amd/shard.py) with the exact-size all-gather-v of the pair lists")
     ap.add_argument("--no-gather", action="store_true", help="strong scaling: keep the pair lists sharded (no exchange step)")
+    ap.add_argument("--input", default="tuples", choices=["tuples", "keys"],
+                    help="tuples: rhj_join_device on the ABI's 16-byte {value, row_id} tuples (the reference's relation layout; default); "
+                         "keys: rhj_join_keys_device on the key columns alone (row id = position: GetRelation of a base relation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-hbm-table", action="store_true")
     ap.add_argument("--order", default="canonical", choices=["canonical", "any"],
@@ -545,8 +548,15 @@ def main():
     import ctypes as C
     m = C.c_uint64(0)
 
+    keysR = keysS = None
+    if args.input == "keys":                    # the key columns alone (contiguous copies; row id = position as in R[:, 1], S[:, 1])
+        keysR, keysS = R[:, 0].contiguous(), S[:, 0].contiguous()
+
     def step():
-        rc = rhj.lib.rhj_join_device(R.data_ptr(), w["nR"], S.data_ptr(), w["nS"], out.data_ptr(), cap, C.byref(m))
+        if keysR is not None:
+            rc = rhj.lib.rhj_join_keys_device(keysR.data_ptr(), w["nR"], keysS.data_ptr(), w["nS"], out.data_ptr(), cap, C.byref(m))
+        else:
+            rc = rhj.lib.rhj_join_device(R.data_ptr(), w["nR"], S.data_ptr(), w["nS"], out.data_ptr(), cap, C.byref(m))
         if rc != 0:
             raise RuntimeError("rhj_join_device rc=%d" % rc)
 
@@ -614,6 +624,9 @@ def main():
         count_bytes = 16 * nS + 16 * nR
         scatter_bytes = 32 * (nR + nS)                    # 16 B read + 16 B written per AoS tuple
         hist_bytes = 16 * (nR + nS)                       # AoS key read (stride-16)
+        if args.input == "keys":                          # SURVEY.md 8(d), column form: 8*n histogram read, 8*n read + 16*n written by the scatter
+            scatter_bytes = 24 * (nR + nS)
+            hist_bytes = 8 * (nR + nS)
 
         def gbs(b, ms):
             return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -623,7 +636,8 @@ def main():
         # scatter = 48*n per relation, WHATEVER the number of passes the implementation takes (a second pass is
         # this implementation's choice, not algorithmic work)
         part_bytes = hist_bytes + scatter_bytes
-        part_formula = "48*n, both relations: 16*n histogram read + 16*n read + 16*n written by the scatter (SURVEY.md 8d, AoS)"
+        part_formula = ("48*n, both relations: 16*n histogram read + 16*n read + 16*n written by the scatter (SURVEY.md 8d, AoS)" if args.input == "tuples"
+                        else "32*n, both relations: 8*n histogram read + 8*n read + 16*n written by the scatter (SURVEY.md 8d, key columns)")
         if w["bits"] <= 8:        # one pass: per-tile histogram, scan, LDS-staged scatter
             part = {"ms": part_ms, "GBps": gbs(part_bytes, part_ms), "algorithmic_bytes": part_bytes,
                     "formula": part_formula,
@@ -704,7 +718,7 @@ def main():
             "config": {"workload": w["name"], "id": args.workload, "nR": nR, "nS": nS, "radix_bits": w["bits"],
                        "matches": M, "parallelism": "independent join per GPU" if world > 1 else "1 GPU",
                        "path": st["path"], "sub_bits": st["sub_bits"], "pass1_bits": st["pass1_bits"], "timing": args.timing,
-                       "order": args.order, "radix_bits_used": st["radix_bits"],
+                       "order": args.order, "radix_bits_used": st["radix_bits"], "input": ("16-byte {value, row_id} tuples (the ABI's relation layout)" if args.input == "tuples" else "key columns, row id = position (rhj_join_keys_device)"),
                        "stage_times": ("events of the timed steps" if args.timing == 2 else
                                        "second pass of %d steps with per-stage events (the timed steps ran with timing %d)" % (stage_steps, args.timing)),
                        "units": st["units"], "max_build_side": st["max_build"],

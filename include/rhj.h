@@ -257,6 +257,13 @@ int rhj_join_device(const rhj_tuple *d_R, uint64_t nR,
                     rhj_result_tuple *d_out, uint64_t out_capacity,
                     uint64_t *matches);
 
+/* The join of two relations given as KEY COLUMNS: tuple i of a relation is {keys[i], i} — what GetRelation makes of a base
+ * relation (inter_res.c:199-204, :223-227: row_id = i).  On the two-pass partition (9..15 radix bits) its first pass reads the
+ * columns themselves, 8 bytes a tuple instead of the 16 of an rhj_tuple; elsewhere the tuples are built first and the ordinary
+ * join runs.  Same pairs, same order as rhj_join_device() on the materialised relations. */
+int  rhj_join_keys_device(const uint64_t *d_keysR, uint64_t nR, const uint64_t *d_keysS, uint64_t nS, rhj_result_tuple *d_out,
+                          uint64_t out_capacity, uint64_t *matches);
+
 /* The stable radix partition alone (SerialReorderArray, preprocess.c:302-362):
  * d_out[n] partitioned tuples, h_hist[2^bits] counts, h_psum[2^bits] starts
  * (-1 for an empty bucket as preprocess.c:336-347 leaves it).  Host arrays may

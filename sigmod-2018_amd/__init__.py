@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "RadixHashJoin", "Filter", "InsertResult", "InsertRowIdResult", "GetResultNum", "FindResultRowId",
     "FindResultTuples", "FreeResult", "PrintResult", "FreeRelation", "SchedulerInit", "SchedulerDestroy",
     "rhj_set_radix_bits", "rhj_get_radix_bits", "rhj_set_empty_mode", "rhj_set_node_pairs", "rhj_set_device", "rhj_get_device",
-    "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_small", "rhj_set_lowradix", "rhj_set_count_in_pass1", "rhj_set_spec", "rhj_last_spec", "rhj_set_exact", "rhj_last_exact", "rhj_set_devices", "rhj_get_devices", "rhj_device_range", "rhj_set_devices_balance", "rhj_plan_device_ranges", "rhj_join_devices", "rhj_gather_pairs_devices", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_partition_device", "rhj_filter_device",
+    "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_small", "rhj_set_lowradix", "rhj_set_count_in_pass1", "rhj_set_spec", "rhj_last_spec", "rhj_set_exact", "rhj_last_exact", "rhj_set_devices", "rhj_get_devices", "rhj_device_range", "rhj_set_devices_balance", "rhj_plan_device_ranges", "rhj_join_devices", "rhj_gather_pairs_devices", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_join_keys_device", "rhj_partition_device", "rhj_filter_device",
     "rhj_register_relation_map", "rhj_unregister_relation_map", "rhj_registered_columns", "rhj_pinned_ranges",
     "rhj_bucket_histogram_device", "rhj_select_bucket_range_device", "rhj_join_device_range", "rhj_pin_refusals",
     "rhj_release", "rhj_last_stats", "rhj_version",
@@ -149,6 +149,8 @@ def load_library(path=None):
     L.rhj_auto_radix_bits.restype = C.c_int
     L.rhj_set_timing.argtypes = [C.c_int]
     L.rhj_join_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+    if hasattr(L, "rhj_join_keys_device"):
+        L.rhj_join_keys_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
     L.rhj_partition_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rhj_filter_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char, C.c_uint64, C.c_void_p, u64p]
     L.rhj_register_relation_map.argtypes = [C.POINTER(RelationMap), C.c_int]

@@ -92,6 +92,7 @@ struct Ctx {
     int         no_exact = 1;        // 1: never launch k_join_exact (the default: it measured slower than the gather kernels, profiles/README.md r04a; env RHJ_EXACT=1 / rhj_set_exact(1) turn it on)
     int         exact_score = 2;     // > 0: launch it where it applies (a join it did adds 1, up to 4; one it handed back for its input takes 2 off)
     int         exact_skipped = 0;   // eligible joins not given to it since the score went to zero: every 16th tries again
+    int         cols_input = 0;      // this join's inputs are key columns (rhj_join_keys_device): pass 1 of the two-pass partition reads 8 bytes a tuple
     int         last_exact = 0;      // the last join: 0 not launched, 1 k_join_exact did the join, 2 it handed over (rhj_last_exact)
     int         lo_override = 0;     // RHJ_LO_BITS: pass-1 digit bits of the two-pass partition (experiments; default bits / 2)
     int         seen_wide = 0;       // a join of this process needed 16-byte intermediates: launch those kernels from now on
@@ -227,7 +228,9 @@ int ctx_init()
     {
         const void *lp[] = {(const void *)k_local_part<false, true, false>, (const void *)k_local_part<false, true, true>,
                             (const void *)k_local_part<false, false, true>, (const void *)k_local_part<true, true, false>,
-                            (const void *)k_local_part<true, true, true>,   (const void *)k_local_part<true, false, true>};
+                            (const void *)k_local_part<true, true, true>,   (const void *)k_local_part<true, false, true>,
+                            (const void *)k_local_part<false, true, false, true>, (const void *)k_local_part<false, true, true, true>,
+                            (const void *)k_local_part<false, false, true, true>};
         for (const void *k : lp) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_scatter_runs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
@@ -405,7 +408,7 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     if (ensure(g.summary, sizeof(PlanSummary))) return -1;
     PlanSummary *dsum = (PlanSummary *)g.summary.p;
     RHJ_STAGE(ST_HIST);
-    RHJ_LAUNCH(k_rowid_sample, dim3(1), dim3(1024), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, ps.launch_wide ? 0 : 1, dsum);
+    RHJ_LAUNCH(k_rowid_sample, dim3(1), dim3(1024), 0, g.stream, a0, a1, nrel, force_wide ? 1 : 0, ps.launch_wide ? 0 : 1, dsum, g.cols_input);
     {
         const uint32_t h2_off = (uint32_t)((scatter_lds_bytes(lo) + 15) & ~(size_t)15);
         const size_t lds1 = count_in_pass1 ? h2_off + ((size_t)2 << bits) : scatter_lds_bytes(lo);
@@ -414,8 +417,11 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         const dim3 grid1(count_in_pass1 ? strips : max1, nrel);
         const bool ranged = a0.range_span != 0;
 #define RHJ_LP(R, H, D) RHJ_LAUNCH((k_local_part<R, H, D>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, 0, lo, lo, hi, dsum, h2_off)
-        if (ranged) { if (!count_in_pass1) RHJ_LP(true, false, true); else if (want_dig) RHJ_LP(true, true, true); else RHJ_LP(true, true, false); }
-        else        { if (!count_in_pass1) RHJ_LP(false, false, true); else if (want_dig) RHJ_LP(false, true, true); else RHJ_LP(false, true, false); }
+#define RHJ_LPC(H, D) RHJ_LAUNCH((k_local_part<false, H, D, true>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, 0, lo, lo, hi, dsum, h2_off)
+        if (g.cols_input) { if (!count_in_pass1) RHJ_LPC(false, true); else if (want_dig) RHJ_LPC(true, true); else RHJ_LPC(true, false); }   // (never ranged: join_keys)
+        else if (ranged)  { if (!count_in_pass1) RHJ_LP(true, false, true); else if (want_dig) RHJ_LP(true, true, true); else RHJ_LP(true, true, false); }
+        else              { if (!count_in_pass1) RHJ_LP(false, false, true); else if (want_dig) RHJ_LP(false, true, true); else RHJ_LP(false, true, false); }
+#undef RHJ_LPC
 #undef RHJ_LP
     }
     RHJ_STAGE(ST_SCAN);
@@ -1373,6 +1379,33 @@ int rhj_join_device(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uin
     RhjApiLock api_lock;
     uint64_t m = 0;
     const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, false, nullptr, &m);
+    if (matches) *matches = m;
+    return rc;
+}
+
+/* The join of two relations given as KEY COLUMNS: tuple i of a relation is {keys[i], i} — what GetRelation makes of a base
+ * relation (inter_res.c:199-204, :223-227: row_id = i) — without materialising the 16-byte tuples: on the two-pass partition
+ * (9..15 radix bits) pass 1 reads the columns themselves, 8 bytes a tuple instead of 16 (the north_star's "coalesced uint64
+ * column loads"); on every other path the tuples are built first (one streaming kernel) and the ordinary join runs.  Same
+ * pairs, same order as rhj_join_device on the materialised relations. */
+int rhj_join_keys_device(const uint64_t *d_keysR, uint64_t nR, const uint64_t *d_keysS, uint64_t nS, rhj_result_tuple *d_out,
+                         uint64_t out_capacity, uint64_t *matches)
+{
+    RhjApiLock api_lock;
+    uint64_t m = 0;
+    if (matches) *matches = 0;
+    if (nR >= (1ull << 32) || nS >= (1ull << 32)) return -2;
+    int rc;
+    const bool lowradix = !g.no_lowradix && lowradix_sub_bits(g.bits, nR, nS) != 0;
+    if (!g.order_any && g.bits > PT_MAX_BITS && !lowradix && !g.wide_row_ids && !g.no_fused && !g.force_hbm && nR && nS) {
+        g.cols_input = 1;
+        rc = join_device((const rhj_tuple *)d_keysR, nR, (const rhj_tuple *)d_keysS, nS, d_out, out_capacity, false, nullptr, &m);
+        g.cols_input = 0;
+    } else {
+        if (ctx_init() || ensure(g.inR, (nR ? nR : 1) * sizeof(rhj_tuple)) || ensure(g.inS, (nS ? nS : 1) * sizeof(rhj_tuple))) return -1;
+        if (rhj_build_relation_device(d_keysR, nullptr, nR, (rhj_tuple *)g.inR.p) || rhj_build_relation_device(d_keysS, nullptr, nS, (rhj_tuple *)g.inS.p)) return -1;
+        rc = join_device((const rhj_tuple *)g.inR.p, nR, (const rhj_tuple *)g.inS.p, nS, d_out, out_capacity, false, nullptr, &m);
+    }
     if (matches) *matches = m;
     return rc;
 }

@@ -260,10 +260,10 @@ struct __attribute__((aligned(4))) Tuple12 { uint32_t klo, khi, rid; };
 // until a join of this process needed the 16-byte ones — so a wide sample is reported as an overflow, which makes the
 // caller run the join again with the 16-byte kernels.
 __global__ __launch_bounds__(1024) void k_rowid_sample(RelArgs r0, RelArgs r1, int nrel, int force_wide, int expect_narrow,
-                                                       PlanSummary *summary)
+                                                       PlanSummary *summary, int cols)
 {
     uint32_t mine = force_wide ? 1u : 0u;
-    for (int rel = 0; rel < nrel; ++rel) {
+    for (int rel = 0; rel < nrel && !cols; ++rel) {       // (key columns: the row ids are positions below 2^32)
         const RelArgs &r = rel ? r1 : r0;
         for (uint32_t j = threadIdx.x; j < 2048u; j += 1024u)
             if (j < r.n) mine |= (uint32_t)(r.in[j].row_id >> 32) | (uint32_t)(r.in[r.n - 1 - j].row_id >> 32);
@@ -299,7 +299,9 @@ __global__ __launch_bounds__(1024) void k_rowid_sample(RelArgs r0, RelArgs r1, i
 #define PT_STRIP_N 4
 #endif
 constexpr uint32_t PT_STRIP = PT_STRIP_N;           // tiles a strip, at most (16-bit cells: 15 is the limit; RelArgs::strip: fewer for small inputs)
-template <bool RANGED, bool H2, bool DIG>
+// COL (rhj_join_keys_device): the input is a KEY COLUMN — 8 bytes a tuple, the row id is the position (what GetRelation makes of
+// a base relation: {col[i], i}, inter_res.c:199-204) — instead of the ABI's 16-byte tuples: pass 1 reads half the bytes.
+template <bool RANGED, bool H2, bool DIG, bool COL = false>
 __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1, int shift, int bits, int next_shift, int next_bits,
                                                          PlanSummary *summary, uint32_t h2_off)
 {
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     const uint64_t beg = (uint64_t)tile * PT_TILE;
     const uint32_t count = (uint32_t)min((uint64_t)PT_TILE, r.n - beg);
     const uint4 *in = reinterpret_cast<const uint4 *>(r.in) + beg;
+    const uint2 *col = reinterpret_cast<const uint2 *>(r.in) + beg;           // COL: r.in is the key column
 
     for (uint32_t i = threadIdx.x; i < PT_WAVES * bins; i += PT_BLOCK) wcnt[i] = 0;
 
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     for (int k = 0; k < PT_V; ++k) {
         const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
         ok[k] = i < count;
-        if (ok[k]) t[k] = in[i];
+        if (COL) { if (ok[k]) { const uint2 kv = col[i]; t[k] = make_uint4(kv.x, kv.y, (uint32_t)(beg + i), (uint32_t)((beg + i) >> 32)); } }
+        else if (ok[k]) t[k] = in[i];
     }
     __syncthreads();
 

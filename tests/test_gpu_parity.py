@@ -245,6 +245,31 @@ def test_speculation_on_gathered_build_sides_both_kinds_of_units(rhj, oracle):
         rhj.lib.rhj_set_spec(1)
 
 
+@pytest.mark.parametrize("bits,nR,nS", [(4, 30_000, 50_000), (8, 300_000, 500_000), (9, 700_000, 900_000), (12, 2_000_000, 3_000_000),
+                                        (10, 8_000_000, 8_000_000), (14, 1_000_000, 5_000_000)])
+def test_join_of_key_columns(rhj, oracle, bits, nR, nS):
+    """rhj_join_keys_device: relations given as key columns, row id = position (what GetRelation makes of a base relation,
+    inter_res.c:199-204).  On 9..15 bits pass 1 of the partition reads the columns themselves (k_local_part<., ., ., COL>: 8 bytes a
+    tuple); elsewhere the tuples are built first.  The pairs are the oracle's on {keys[i], i}."""
+    import ctypes as C
+    import torch
+    R = oracle.generate(nR, 0, 0, 0.0, 301)
+    S = oracle.generate(nS, 1, nR, 0.0, 302)
+    assert (R["row_id"] == np.arange(nR, dtype=np.uint64)).all()
+    want = oracle.join(R, S, bits)
+    rhj.set_bits(bits)
+    set_path(rhj, "fused")
+    kR = torch.from_numpy(R["value"].view(np.int64).copy()).to(rhj.dev)
+    kS = torch.from_numpy(S["value"].view(np.int64).copy()).to(rhj.dev)
+    out = torch.empty((len(want) + 8, 2), dtype=torch.int64, device=rhj.dev)
+    m = C.c_uint64(0)
+    for rep in range(2):                                         # (twice: the speculation's score and the workspace carry over)
+        assert rhj.lib.rhj_join_keys_device(kR.data_ptr(), nR, kS.data_ptr(), nS, out.data_ptr(), out.shape[0], C.byref(m)) == 0
+        assert m.value == len(want) and (rhj.pairs_to_numpy(out)[:m.value] == want).all(), (bits, rep)
+    # a buffer that is too small: the count comes back, rc 1
+    assert rhj.lib.rhj_join_keys_device(kR.data_ptr(), nR, kS.data_ptr(), nS, out.data_ptr(), 10, C.byref(m)) == 1 and m.value == len(want)
+
+
 def test_row_id_width_is_speculated_and_a_wrong_guess_runs_again():
     """The 16-byte kernels of the two-pass partition are not launched until a join of the process has needed them: the first
     join with wide row ids is reported as an overflow by the sample and run again wide; later joins launch both widths."""
