@@ -76,7 +76,8 @@ struct FusedArgs {
 // tuple, an overflow stash that ran full — is handed to k_join_walk, which rebuilds the index and walks it again.
 struct FjWalkItem {
     uint32_t unit;
-    uint32_t flags;           // bit 0: the unit's build tuples were LDS-resident in k_join_fused (its stash keeps runs for multi-match
+    uint32_t flags;           // bit 3 (8): nothing was stashed for this unit (k_join_spec's direct path): every tuple is recounted from the index;
+                              // bit 0: the unit's build tuples were LDS-resident in k_join_fused (its stash keeps runs for multi-match
                               // tuples); bit 1: k_join_fused hashed with FjHashT<true> — the stash's "a tag hit was a foreign key"
                               // bit is a statement about THAT hash's tags, so the walk must index with the same one
     uint64_t base;            // first output position of the unit (its look-back is done)
@@ -1062,7 +1063,7 @@ __device__ __forceinline__ uint32_t fj_walk_group(const IX &X, const FjGather<N3
             const uint32_t slot = ne + (uint32_t)__popcll(mk & lt);
             if (isrec && slot < FJ_REC_CAP) rec[slot] = make_uint4(g[j].z, pr[j], (ks[j] * WAVE + lane) | (cc << 8), 0u);
             ne += (uint32_t)__popcll(mk);
-            cannot = cannot || (eq && cc >= 255u);     // (the ordinal has eight bits)
+            cannot = cannot || (eq && cc >= 65535u);   // (the ordinal has sixteen bits)
 #pragma unroll
             for (int k = 0; k < V; ++k)
                 if (ks[j] == (uint32_t)k && eq) { if (cc == 0) first[k] = g[j].z; c[k] = cc + 1u; }
@@ -1348,14 +1349,25 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
 #if defined(FJ_ABL_NOSER) || defined(FJ_ABL_G8)
         if (false) {
 #else
-        if (total != spec_total || (!MAYRES && unit_needs_index)) {
-#endif   // (workgroup-uniform; a gathered unit's pairs are out already: nothing left to walk)
+        if (total != spec_total) {
+#endif   // (workgroup-uniform)
             if (threadIdx.x == 0) __hip_atomic_store(f.ticket + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         if (threadIdx.x == 0) { a.unit_count[u] = total; sh_base = spec_base; }
         __syncthreads();
-        if (!emitting || !MAYRES) continue;
+        if (!MAYRES) {
+            // a gathered unit's pairs are out — unless a group had more second-and-later matches than its wave's piece holds or a
+            // tuple more matches than an ordinal counts (hot keys among the build side's duplicates): the counts, and with them the
+            // total just checked, are exact all the same, so the speculation stands and k_join_walk writes this unit's pairs again,
+            // all of them, at the predicted base — from the index alone (flag 8: nothing was stashed)
+            if (unit_needs_index && emitting && threadIdx.x == 0) {
+                const uint32_t at = atomicAdd(f.ticket + 2, 1u);
+                f.walk[at] = FjWalkItem{u, 8u, sh_base};
+            }
+            continue;
+        }
+        if (!emitting) continue;
         if (!unit_needs_index && !unit_res_dup) {
             if (ovf_total != 0) fj_emit_stream<true, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, MAYRES ? 0u : npatch);
             else                fj_emit_stream<false, N32>(f, u, sh_base, wsum, O.buf, O.table, &sh_grab, 0u);
@@ -1517,7 +1529,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_fused(FusedArgs f, uint32_t l
 //   position (rhjoin.c:141-250).
 template <bool RES, bool N32, bool H32>
 __device__ __forceinline__ void fj_walk_unit(const FusedArgs &f, uint32_t lds_bytes, uint32_t *tbl, uint32_t u, uint64_t base,
-                                             uint32_t *wsum, uint32_t *sh_pick)
+                                             uint32_t *wsum, uint32_t *sh_pick, bool nostash = false)
 {
     const JoinArgs &a = f.j;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1568,10 +1580,11 @@ __device__ __forceinline__ void fj_walk_unit(const FusedArgs &f, uint32_t lds_by
                 okk[h][k] = i < un.count;
                 fpt[h][k] = false;
                 q[h][k] = okk[h][k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
-                const uint32_t sb = okk[h][k] ? scnt[i] : 0;
+                // nostash: nothing was parked for this unit — every tuple counts as "saturated, some tag hit foreign": recounted and walked in full
+                const uint32_t sb = !okk[h][k] ? 0u : nostash ? 0xffu : scnt[i];
                 c[h][k] = sb & 0x7fu;
                 fpt[h][k] = RES || (sb & 0x80u) != 0;      // (a resident unit's stash keeps runs, not first matches, for multi-match tuples)
-                const uint2 fr = okk[h][k] ? srow[i] : make_uint2(0, 0);
+                const uint2 fr = (okk[h][k] && !nostash) ? srow[i] : make_uint2(0, 0);
                 flo[h][k] = fr.x; fhi[h][k] = N32 ? 0u : fr.y;
             }
         }
@@ -1677,7 +1690,7 @@ __global__ __launch_bounds__(FJ_BLOCK) void k_join_walk(FusedArgs f, uint32_t ld
             else        { if (res) fj_walk_unit<true, false, true>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
                           else     fj_walk_unit<false, false, true>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick); }
         } else {
-            if (narrow) fj_walk_unit<false, true, false>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
+            if (narrow) fj_walk_unit<false, true, false>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick, (it.flags & 8u) != 0);
             else        fj_walk_unit<false, false, false>(f, lds_bytes, tbl, it.unit, it.base, wsum, &sh_pick);
         }
     }

@@ -212,8 +212,9 @@ def test_speculation_on_gathered_build_sides_both_kinds_of_units(rhj, oracle):
     and half by R (fj_group_direct: first candidates four a lane, the others lane by lane, second and later matches as records,
     the groups of a unit chained in LDS).  Uniform draws (0..9 matches an R tuple); draws from half of R's keys (twice the
     matches, ~145 records a group); from an eighth (eight matches a key, ~224 records a group); from the FIRST quarter of R's
-    tuples (whole groups of tuples with four matches each: more than the 512 records a wave keeps: handed over); one R tuple with
-    300 matches (the ordinal has eight bits: handed over).  The pairs are the oracle's in every case."""
+    tuples (whole groups of tuples with four matches each: more than the 512 records a wave keeps — such a unit's pairs are written
+    again by k_join_walk, from the index alone, and the speculation stands); one R tuple with 700 matches (its group's records
+    run out likewise).  The pairs are the oracle's in every case."""
     bits, n = 10, 8_000_000
     rhj.set_bits(bits)
     set_path(rhj, "fused")
@@ -232,15 +233,15 @@ def test_speculation_on_gathered_build_sides_both_kinds_of_units(rhj, oracle):
         some = rng.permutation(n)                                    # (a random half / eighth of R's tuples: mixed with the others inside every group)
         run(helpers.make_rel(R["value"][some[rng.integers(0, n // 2, n)]]), 1)
         run(helpers.make_rel(R["value"][some[rng.integers(0, n // 8, n)]]), 1)
-        run(helpers.make_rel(R["value"][rng.integers(0, n // 4, n)]), 2)     # the FIRST quarter of R's tuples: whole groups of them in every bucket
+        run(helpers.make_rel(R["value"][rng.integers(0, n // 4, n)]), 1)     # the FIRST quarter of R's tuples: whole groups of them in every bucket
         S3 = S.copy()
         hr = np.bincount((R["value"] & np.uint64(1023)).astype(np.int64), minlength=1024)
         hs = np.bincount((S3["value"] & np.uint64(1023)).astype(np.int64), minlength=1024)
         b0 = int(np.nonzero(hr >= hs)[0][0])                         # a bucket R probes (rhjoin.c:86)
         k0 = R["value"][np.nonzero((R["value"] & np.uint64(1023)) == np.uint64(b0))[0][7]]
         same_bucket = np.nonzero((S3["value"] & np.uint64(1023)) == np.uint64(b0))[0]
-        S3["value"][same_bucket[:300]] = k0                          # (the bucket's sizes stay what they were)
-        run(S3, 2)
+        S3["value"][same_bucket[:700]] = k0                          # (the bucket's sizes stay what they were)
+        run(S3, 1)
     finally:
         rhj.lib.rhj_set_spec(1)
 
