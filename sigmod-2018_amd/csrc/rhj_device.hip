@@ -94,6 +94,7 @@ struct Ctx {
     int         exact_skipped = 0;   // eligible joins not given to it since the score went to zero: every 16th tries again
     int         cols_input = 0;      // this join's inputs are key columns (rhj_join_keys_device): pass 1 of the two-pass partition reads 8 bytes a tuple
     int         last_exact = 0;      // the last join: 0 not launched, 1 k_join_exact did the join, 2 it handed over (rhj_last_exact)
+    int         msd = 0;             // RHJ_MSD=1: pass 1 of the two-pass partition takes the HIGH bits of the radix, pass 2 the low ones (A/B)
     int         lo_override = 0;     // RHJ_LO_BITS: pass-1 digit bits of the two-pass partition (experiments; default bits / 2)
     int         seen_wide = 0;       // a join of this process needed 16-byte intermediates: launch those kernels from now on
     int         no_lowradix = 0;     // 1: never take the low-radix path (env RHJ_NO_LOWRADIX; rhj_set_lowradix(0)): big joins on few bits go tiled
@@ -159,6 +160,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_NO_SPEC"))) g.no_spec = atoi(e);
         if ((e = getenv("RHJ_EXACT"))) g.no_exact = !atoi(e);
         if ((e = getenv("RHJ_LO_BITS"))) g.lo_override = atoi(e);
+        if ((e = getenv("RHJ_MSD"))) g.msd = atoi(e);
         if ((e = getenv("RHJ_NO_COUNT_IN_PASS1"))) g.no_count_in_pass1 = atoi(e);
         g.stamps = getenv("RHJ_STAMPS") != nullptr;
         if ((e = getenv("RHJ_TIMING"))) g.timing = atoi(e);
@@ -347,6 +349,11 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     int lo = ps.lo_bits ? ps.lo_bits : bits / 2;
     if (!ps.lo_bits && g.lo_override > 0 && g.lo_override < bits && bits - g.lo_override <= PT_MAX_BITS && g.lo_override <= PT_MAX_BITS) lo = g.lo_override;   // (RHJ_LO_BITS: experiments)
     const int hi = bits - lo;
+    // which end of the radix pass 1 takes: the low `lo` bits (pass 2 then gathers by them and scatters by the high `hi`), or —
+    // msd — the high `lo` bits, pass 2 the low `hi` (same buckets, same order inside them: either pass is stable and a pass-2
+    // tile reads its runs in tile order).  The low-radix path counts on pass 1 taking the caller's own low bits.
+    const bool msd = g.msd && !ps.lo_bits;
+    const int sh1 = msd ? hi : 0, sh2 = msd ? 0 : lo;
     const uint32_t bins1 = 1u << lo, bins2 = 1u << hi;
     if (ensure(g.slice_tot, (size_t)2 * bins * FH_SLICES * 4) || ensure(g.sbase, (size_t)2 * bins * FH_SLICES * 4)) return -1;
     RelArgs a0 = ps.r[0], a1 = nrel > 1 ? ps.r[1] : none;
@@ -416,8 +423,8 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         for (int i = 0; i < nrel; ++i) strips = ar[i]->groups * ar[i]->parts > strips ? ar[i]->groups * ar[i]->parts : strips;
         const dim3 grid1(count_in_pass1 ? strips : max1, nrel);
         const bool ranged = a0.range_span != 0;
-#define RHJ_LP(R, H, D) RHJ_LAUNCH((k_local_part<R, H, D>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, 0, lo, lo, hi, dsum, h2_off)
-#define RHJ_LPC(H, D) RHJ_LAUNCH((k_local_part<false, H, D, true>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, 0, lo, lo, hi, dsum, h2_off)
+#define RHJ_LP(R, H, D) RHJ_LAUNCH((k_local_part<R, H, D>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, sh1, lo, sh2, hi, dsum, h2_off)
+#define RHJ_LPC(H, D) RHJ_LAUNCH((k_local_part<false, H, D, true>), grid1, dim3(PT_BLOCK), lds1, g.stream, a0, a1, sh1, lo, sh2, hi, dsum, h2_off)
         if (g.cols_input) { if (!count_in_pass1) RHJ_LPC(false, true); else if (want_dig) RHJ_LPC(true, true); else RHJ_LPC(true, false); }   // (never ranged: join_keys)
         else if (ranged)  { if (!count_in_pass1) RHJ_LP(true, false, true); else if (want_dig) RHJ_LP(true, true, true); else RHJ_LP(true, true, false); }
         else              { if (!count_in_pass1) RHJ_LP(false, false, true); else if (want_dig) RHJ_LP(false, true, true); else RHJ_LP(false, true, false); }
@@ -426,16 +433,16 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
     }
     RHJ_STAGE(ST_SCAN);
     if (count_in_pass1)
-        RHJ_LAUNCH((k_group_scan<true>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p);
+        RHJ_LAUNCH((k_group_scan<true>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p, msd ? 1 : 0);
     else {
         const uint32_t hw = (max2 + HR_BLOCK / WAVE - 1) / (HR_BLOCK / WAVE);    // one wave per pass-2 tile
         RHJ_LAUNCH(k_hist_runs, dim3(hw < 4096 ? hw : 4096, nrel), dim3(HR_BLOCK), (size_t)bins2 * 4 * (HR_BLOCK / WAVE), g.stream,
                    b0, b1, hi);
-        RHJ_LAUNCH((k_group_scan<false>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p);
+        RHJ_LAUNCH((k_group_scan<false>), dim3(bins1, nrel, FH_SLICES), dim3(1024), 0, g.stream, b0, b1, hi, (uint32_t *)g.slice_tot.p, msd ? 1 : 0);
     }
     const int staged = bits >= 13;
 #define RHJ_BP(P) RHJ_LAUNCH((k_bucket_psum<P>), dim3(nrel, FH_SLICES), dim3(1024), staged ? (size_t)(bins < 16384u ? bins : 16384u) * 8 : 0, g.stream, lo, hi, \
-                            (const uint32_t *)g.slice_tot.p, (uint32_t *)g.sbase.p, ps.hist, ps.psum, staged)
+                            (const uint32_t *)g.slice_tot.p, (uint32_t *)g.sbase.p, ps.hist, ps.psum, staged, msd ? 1 : 0)
     if (bits <= 10) RHJ_BP(1); else if (bits == 11) RHJ_BP(2); else if (bits == 12) RHJ_BP(4); else RHJ_BP(0);
 #undef RHJ_BP
     RHJ_STAGE(ST_SCATTER);
@@ -449,13 +456,13 @@ int run_partition(PartState &ps, int bits, int nrel, bool force_wide, bool final
         const uint32_t want = ((max2 < sgrid ? max2 : sgrid) + 7u) & ~7u;     // a multiple of the 8 XCDs
         if (launch_narrow && final12)
             RHJ_LAUNCH((k_scatter_runs<true, true>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
-                       lo, hi, search0, (const PlanSummary *)dsum);
+                       sh2, hi, search0, (const PlanSummary *)dsum);
         else if (launch_narrow)
             RHJ_LAUNCH((k_scatter_runs<true, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
-                       lo, hi, search0, (const PlanSummary *)dsum);
+                       sh2, hi, search0, (const PlanSummary *)dsum);
         if (ps.launch_wide)
             RHJ_LAUNCH((k_scatter_runs<false, false>), dim3(want, nrel), dim3(PT_BLOCK), scatter_runs_lds_bytes(hi), g.stream, b0, b1,
-                       lo, hi, search0, (const PlanSummary *)dsum);
+                       sh2, hi, search0, (const PlanSummary *)dsum);
     }
     ps.p2[0] = b0; ps.p2[1] = b1;
     HIP_TRY(hipGetLastError());
@@ -1225,7 +1232,7 @@ static void adopt_knobs(Ctx &d, const Ctx &s)
     d.bits = s.bits; d.null_on_empty = s.null_on_empty; d.force_hbm = s.force_hbm; d.ablate = s.ablate; d.order_any = s.order_any;
     d.no_fused = s.no_fused; d.force_fused = s.force_fused; d.no_resident = s.no_resident; d.wide_row_ids = s.wide_row_ids;
     d.timing = s.timing; d.no_count_in_pass1 = s.no_count_in_pass1; d.no_spec = s.no_spec; d.no_exact = s.no_exact;
-    d.lo_override = s.lo_override; d.no_lowradix = s.no_lowradix; d.no_small = s.no_small; d.small_tiles = s.small_tiles;
+    d.lo_override = s.lo_override; d.msd = s.msd; d.no_lowradix = s.no_lowradix; d.no_small = s.no_small; d.small_tiles = s.small_tiles;
     d.node_pairs = s.node_pairs;
 }
 

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     for (int k = 0; k < PT_V; ++k) {
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
-        if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << (shift + bits + next_bits)) - 1u)) - r.range_lo) < r.range_span;
+        if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << max(shift + bits, next_shift + next_bits)) - 1u)) - r.range_lo) < r.range_span;
         dig[k] = d;
         uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
         for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit
@@ -475,15 +475,26 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
     const uint32_t bins = 1u << bits;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *h = lds_u32 + w * bins;                 // this wave's histogram
-    const uint32_t stride = gridDim.x * (HR_BLOCK / WAVE);
-    for (uint32_t tile2 = blockIdx.x * (HR_BLOCK / WAVE) + w; tile2 < r.tiles; tile2 += stride) {
+    // Which tiles a workgroup takes: `chunk` consecutive pass-1 digits d of ONE group j, its four waves side by side.  The runs of
+    // digits d, d + 1, .. of a pass-1 tile lie next to each other in the digit array, 32 bytes each at 14 bits, so the lines this
+    // workgroup fetches are used whole; with consecutive tile numbers (same d, consecutive j) every run cost a line of its own and
+    // the kernel fetched 5.1 bytes a tuple for the one it counts (100M + 100M at 14 bits: 0.20 -> 0.18 ms; 100M x 1B the same 1.1 ms).
+    const uint32_t bins1 = r.tiles / r.groups;
+    uint32_t chunk = 32;
+    while (chunk > 4u && r.tiles / chunk < 2048u) chunk >>= 1;
+    for (uint32_t qc = blockIdx.x * chunk; qc < r.tiles; qc += gridDim.x * chunk)
+    for (uint32_t qt = qc + w; qt < min(qc + chunk, r.tiles); qt += HR_BLOCK / WAVE) {
+        const uint32_t tj = qt / bins1, tile2 = (qt - tj * bins1) * r.groups + tj;
         for (uint32_t b = lane; b < bins; b += WAVE) h[b] = 0;
         for (uint32_t c0 = 0; c0 < r.group; c0 += WAVE) {
             uint32_t phys, len;
             pt_run_of(r, tile2, c0 + lane, phys, len);
             const uint32_t nrun = min((uint32_t)WAVE, r.group - c0);
             // four runs per wave load: sixteen lanes a run, four digit bytes a lane (the digit array is padded by 64 bytes,
-            // a run's last dword may reach past its end: those bytes are not counted); eight loads in flight
+            // a run's last dword may reach past its end: those bytes are not counted); eight loads in flight.
+            // (The LDS atomics — about two lanes a clock and CU — are this kernel's time, 1.1 ms on 100M x 1B.  Counting by
+            // match-any instead, a byte of every lane a round and the lowest lane of a digit adding the group, took 3.1 ms: runs
+            // are 20 .. 45 bytes, so most rounds run for a few lanes.)
             const uint32_t g4 = lane >> 4, sub4 = (lane & 15u) * 4u;
             for (uint32_t q0 = 0; q0 < nrun; q0 += 32) {
                 uint32_t dw[8], ll[8], pp[8];
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(HR_BLOCK) void k_hist_runs(RelArgs r0, RelArgs r1, 
 // loads, eight in flight: with one digit a thread and 2-byte loads the kernel took 45 us on 100M + 100M tuples), the sums meet
 // in LDS, and the scan along the groups runs there.
 template <bool FROM_PARTS>
-__global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int bits, uint32_t *slice_tot)
+__global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int bits, uint32_t *slice_tot, int msd)
 {
     __shared__ uint32_t acc[8192];                    // [rows of the round][digit]
     __shared__ uint32_t tot[1024];                    // [row chunk][digit]
@@ -618,8 +629,8 @@ __global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int
         carry += all;
         __syncthreads();
     }
-    if (rr == 0)                                      // [relation][slice][bucket = digit << bits1 | d]
-        slice_tot[((size_t)blockIdx.y * FH_SLICES + blockIdx.z) * gridDim.x * bins + ((size_t)b * gridDim.x + d)] = carry;
+    if (rr == 0)                                      // [relation][slice][bucket = digit << bits1 | d, or d << bits | digit (msd)]
+        slice_tot[((size_t)blockIdx.y * FH_SLICES + blockIdx.z) * gridDim.x * bins + (msd ? (size_t)d * bins + b : (size_t)b * gridDim.x + d)] = carry;
 }
 
 // slice totals -> bucket histogram (u64) + exclusive psum of the full radix, and RelArgs::sbase: bucket start + the slices
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(RelArgs r0, RelArgs r1, int
 // (PER > 0: buckets a thread, known at compile time — all slice totals of a thread are loaded at once and stay in registers.)
 template <int PER>
 __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const uint32_t *slice_tot, uint32_t *sbase, uint64_t *hist,
-                                                      uint64_t *psum, int staged)
+                                                      uint64_t *psum, int staged, int msd)
 {
     __shared__ uint64_t sm[1024 / 64 + 1];
     const uint32_t all_bins = 1u << (bits1 + bits), bins = 1u << bits, bins1 = 1u << bits1, zme = blockIdx.y;
@@ -638,6 +649,11 @@ __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const
     uint64_t *h = hist + (size_t)blockIdx.x * all_bins, *p = psum + (size_t)blockIdx.x * all_bins;
     const uint32_t per = PER ? (uint32_t)PER : (all_bins + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, all_bins);
+    // bucket -> its cell of sbase: (pass-1 digit d, slice, pass-2 digit); msd: pass 1 took the HIGH bits, so d = bucket >> bits
+    auto sb_at = [&](uint32_t bk) -> size_t {
+        const uint32_t d = msd ? bk >> bits : bk & (bins1 - 1u), dg = msd ? bk & (bins - 1u) : bk >> bits1;
+        return ((size_t)d * FH_SLICES + zme) * bins + dg;
+    };
     uint64_t mine = 0;
     if (PER) {
         uint32_t c[PER ? PER : 1][FH_SLICES];
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const
             const uint32_t bk = b0 + i;
             if (bk < all_bins) {
                 if (zme == 0) { h[bk] = t[i]; p[bk] = base; }
-                sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + front[i];   // (mod 2^32,
+                sb[sb_at(bk)] = (uint32_t)base + front[i];   // (mod 2^32,
                 base += t[i];                                                                                            //  like the tile counts)
             }
         }
@@ -692,7 +708,7 @@ __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const
             for (uint32_t i = i0; i < i0 + cper; ++i) {
                 const uint32_t bk = c0 + i, t = tl[i];
                 if (zme == 0) { h[bk] = t; p[bk] = base; }
-                sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + fl2[i];
+                sb[sb_at(bk)] = (uint32_t)base + fl2[i];
                 base += t;
             }
             carry += all;
@@ -727,7 +743,7 @@ __global__ __launch_bounds__(1024) void k_bucket_psum(int bits1, int bits, const
 #pragma unroll
                 for (uint32_t z = 0; z < FH_SLICES; ++z) { front += z < zme ? c[i][z] : 0u; t += c[i][z]; }
                 if (zme == 0) { h[bk] = t; p[bk] = base; }
-                sb[((size_t)(bk & (bins1 - 1u)) * FH_SLICES + zme) * bins + (bk >> bits1)] = (uint32_t)base + front;
+                sb[sb_at(bk)] = (uint32_t)base + front;
                 base += t;
             }
         }
