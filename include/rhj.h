@@ -206,9 +206,18 @@ int  rhj_get_devices(void);
 int  rhj_device_range(int bits, int n, int d, uint32_t *lo, uint32_t *hi);
 /* rhj_set_devices_balance(1) / env RHJ_DEVICES_BALANCE=hist: rhj_join_devices cuts the ranges by histR + histS (two histogram
  * launches on the library's device and one read-back) instead of equal widths — for skewed keys; rhj_plan_device_ranges() is
- * that plan (cuts[d] .. cuts[d + 1] = device d's buckets; needs no GPU).  Ranges are cut BETWEEN buckets. */
-void rhj_set_devices_balance(int by_histogram);
+ * that plan (cuts[d] .. cuts[d + 1] = device d's buckets; needs no GPU).  These ranges are cut BETWEEN buckets. */
+void rhj_set_devices_balance(int mode);
 int  rhj_plan_device_ranges(const uint64_t *histR, const uint64_t *histS, int bits, int n, uint32_t *cuts);
+/* rhj_set_devices_balance(2) / RHJ_DEVICES_BALANCE=slice: the cuts may also fall INSIDE a hot bucket (one that holds at least
+ * 1 / (2 n) of all tuples): the devices on either side of such a cut both partition the bucket's build side and share its probe
+ * tuples ("a hot bucket's probe side across GPUs with the build side replicated") — a join on few radix bits, or
+ * one with a key that dominates, still spreads over all devices.  rhj_plan_device_slices() is that plan: device d joins from
+ * (cut_bucket[d], cut_off[d]) to (cut_bucket[d + 1], cut_off[d + 1]) in (bucket, position among the bucket's probe tuples)
+ * order, n + 1 cuts; rhj_cut_to_slice() turns two neighbouring cuts into the arguments of rhj_join_device_slice().  No GPU needed. */
+int  rhj_plan_device_slices(const uint64_t *histR, const uint64_t *histS, int bits, int n, uint32_t *cut_bucket, uint64_t *cut_off);
+void rhj_cut_to_slice(uint32_t b0, uint64_t o0, uint32_t b1, uint64_t o1, uint32_t *bucket_lo, uint32_t *bucket_hi,
+                      uint64_t *first_skip, uint64_t *last_end);
 int  rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *const *d_S, uint64_t nS,
                       rhj_result_tuple *const *out, const uint64_t *capacity, uint64_t *matches);
 int  rhj_gather_pairs_devices(const rhj_result_tuple *const *lists, const uint64_t *matches, int dst_device,
@@ -293,6 +302,14 @@ int rhj_bucket_histogram_device(const rhj_tuple *d_in, uint64_t n, uint64_t *d_h
  * caller's radix). */
 int rhj_join_device_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS,
                           uint32_t bucket_lo, uint32_t bucket_hi,
+                          rhj_result_tuple *d_out, uint64_t out_capacity, uint64_t *matches);
+/* A share cut inside buckets: the buckets [bucket_lo, bucket_hi), of the first only the probe tuples from first_skip on, of the
+ * last (bucket_hi - 1) only those before last_end (0: all) — positions among the tuples of the bucket's probe side (R when
+ * |R_b| >= |S_b|, rhjoin.c:86) in partition order.  The result: the canonical list's pairs of exactly those probe tuples
+ * (rhjoin.c:141-217 walks a bucket's probe tuples in order), so shares that tile (bucket, position) concatenate to the
+ * canonical result.  The foreign-key speculation is not tried on a share that cuts a bucket. */
+int rhj_join_device_slice(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS,
+                          uint32_t bucket_lo, uint32_t bucket_hi, uint64_t first_skip, uint64_t last_end,
                           rhj_result_tuple *d_out, uint64_t out_capacity, uint64_t *matches);
 int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t bucket_lo, uint32_t bucket_hi,
                                    rhj_tuple *d_out, uint64_t capacity, uint64_t *count);

@@ -26,9 +26,9 @@ ABI_SYMBOLS = [
     "RadixHashJoin", "Filter", "InsertResult", "InsertRowIdResult", "GetResultNum", "FindResultRowId",
     "FindResultTuples", "FreeResult", "PrintResult", "FreeRelation", "SchedulerInit", "SchedulerDestroy",
     "rhj_set_radix_bits", "rhj_get_radix_bits", "rhj_set_empty_mode", "rhj_set_node_pairs", "rhj_set_device", "rhj_get_device",
-    "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_small", "rhj_set_lowradix", "rhj_set_count_in_pass1", "rhj_set_spec", "rhj_last_spec", "rhj_set_exact", "rhj_last_exact", "rhj_set_devices", "rhj_get_devices", "rhj_device_range", "rhj_set_devices_balance", "rhj_plan_device_ranges", "rhj_join_devices", "rhj_gather_pairs_devices", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_join_keys_device", "rhj_partition_device", "rhj_filter_device",
+    "rhj_set_stream", "rhj_set_force_hbm_table", "rhj_set_fused", "rhj_set_resident", "rhj_set_small", "rhj_set_lowradix", "rhj_set_count_in_pass1", "rhj_set_spec", "rhj_last_spec", "rhj_set_exact", "rhj_last_exact", "rhj_set_devices", "rhj_get_devices", "rhj_device_range", "rhj_set_devices_balance", "rhj_plan_device_ranges", "rhj_plan_device_slices", "rhj_cut_to_slice", "rhj_join_devices", "rhj_gather_pairs_devices", "rhj_set_order", "rhj_get_order", "rhj_auto_radix_bits", "rhj_set_timing", "rhj_join_device", "rhj_join_keys_device", "rhj_partition_device", "rhj_filter_device",
     "rhj_register_relation_map", "rhj_unregister_relation_map", "rhj_registered_columns", "rhj_pinned_ranges",
-    "rhj_bucket_histogram_device", "rhj_select_bucket_range_device", "rhj_join_device_range", "rhj_pin_refusals",
+    "rhj_bucket_histogram_device", "rhj_select_bucket_range_device", "rhj_join_device_range", "rhj_join_device_slice", "rhj_pin_refusals",
     "rhj_release", "rhj_last_stats", "rhj_version",
 ]
 # every symbol include/rhj_inter.h declares (device-resident intermediate results)
@@ -141,6 +141,12 @@ def load_library(path=None):
         L.rhj_device_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rhj_set_devices_balance.argtypes = [C.c_int]
         L.rhj_plan_device_ranges.argtypes = [u64p, u64p, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+        if hasattr(L, "rhj_plan_device_slices"):
+            L.rhj_plan_device_slices.argtypes = [u64p, u64p, C.c_int, C.c_int, C.POINTER(C.c_uint32), u64p]
+            L.rhj_cut_to_slice.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p, u64p]
+            L.rhj_cut_to_slice.restype = None
+            L.rhj_join_device_slice.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                                C.c_void_p, C.c_uint64, u64p]
         L.rhj_join_devices.argtypes = [C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_void_p), u64p, u64p]
         L.rhj_gather_pairs_devices.argtypes = [C.POINTER(C.c_void_p), u64p, C.c_int, C.c_void_p, C.c_uint64, u64p]
     L.rhj_set_order.argtypes = [C.c_int]
@@ -204,7 +210,8 @@ class RHJ:
     def join_device(self, dR, dS, capacity=None, count_only=False, bucket_range=None):
         """dR, dS: int64 tensors [n,2] (value,row_id).  Returns (pairs tensor [M,2], matches).
         bucket_range = (lo, hi): only the buckets [lo, hi) of the current radix (rhj_join_device_range: one rank's share of a
-        sharded join; the partition drops the other buckets while it reads the relations)."""
+        sharded join; the partition drops the other buckets while it reads the relations); (lo, hi, first_skip, last_end): a share
+        cut inside its first / last bucket (rhj_join_device_slice)."""
         torch = self.torch
         nR, nS = dR.shape[0], dS.shape[0]
         m = C.c_uint64(0)
@@ -212,6 +219,9 @@ class RHJ:
         def call(out_ptr, cap):
             if bucket_range is None:
                 rc = self.lib.rhj_join_device(dR.data_ptr(), nR, dS.data_ptr(), nS, out_ptr, cap, C.byref(m))
+            elif len(bucket_range) == 4:
+                rc = self.lib.rhj_join_device_slice(dR.data_ptr(), nR, dS.data_ptr(), nS, int(bucket_range[0]), int(bucket_range[1]),
+                                                    int(bucket_range[2]), int(bucket_range[3]), out_ptr, cap, C.byref(m))
             else:
                 rc = self.lib.rhj_join_device_range(dR.data_ptr(), nR, dS.data_ptr(), nS, int(bucket_range[0]), int(bucket_range[1]),
                                                     out_ptr, cap, C.byref(m))

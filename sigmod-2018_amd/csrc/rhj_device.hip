@@ -101,6 +101,7 @@ struct Ctx {
     int         no_small = 0;        // 1: never take the three-launch path for small joins (env RHJ_NO_SMALL, rhj_set_small(0))
     uint32_t    small_tiles = 512;   // largest relation, in 8192-tuple tiles, the small path takes (env RHJ_SMALL_TILES; at most SM_MAX_TILES)
     uint32_t    range_lo = 0, range_span = 0;   // rhj_join_device_range: the buckets this call joins (span 0: all of them)
+    uint64_t    slice_skip = 0, slice_end = 0;  // rhj_join_device_slice: the first bucket's probe tuples from slice_skip on, the last bucket's before slice_end (0: all)
     int         cus = 256;           // compute units of the device (one fused workgroup each)
     uint64_t    node_pairs = 65535;
     hipEvent_t  ev[ST_N + 1] = {};
@@ -133,7 +134,7 @@ thread_local Ctx *g_cur = &g_all[0];
 #define g (*g_cur)
 int g_ndev = 1;                      // devices a join is sharded over (rhj_set_devices, env RHJ_DEVICES)
 int g_ndev_env = 0;                  // RHJ_DEVICES as read at load time (applied by the first call that can shard)
-int g_balance = 0;                   // 1: rhj_join_devices cuts the bucket ranges by histR + histS instead of equal widths (rhj_set_devices_balance, env RHJ_DEVICES_BALANCE=hist)
+int g_balance = 0;                   // rhj_join_devices: 1 cuts the bucket ranges by histR + histS instead of equal widths, 2 also cuts INSIDE hot buckets (rhj_set_devices_balance, env RHJ_DEVICES_BALANCE=hist / slice)
 int g_same_device = 0;               // RHJ_DEVICES_SAME=1 (tests): every context on the library's own device — n streams and workspaces on one GPU
 
 // environment defaults are read once at load time; the rhj_set_* calls override them
@@ -144,7 +145,7 @@ struct EnvDefaults {
         if ((e = getenv("RHJ_DEVICE"))) g.device = atoi(e);
         if ((e = getenv("RHJ_DEVICES"))) g_ndev_env = atoi(e);
         if ((e = getenv("RHJ_DEVICES_SAME"))) g_same_device = atoi(e);
-        if ((e = getenv("RHJ_DEVICES_BALANCE"))) g_balance = strcmp(e, "hist") == 0;
+        if ((e = getenv("RHJ_DEVICES_BALANCE"))) g_balance = strcmp(e, "slice") == 0 ? 2 : strcmp(e, "hist") == 0 ? 1 : 0;
         if ((e = getenv("RHJ_RADIX_BITS"))) { int b = atoi(e); if (b >= 1 && b <= 15) g.bits = b; }
         if ((e = getenv("RHJ_EMPTY"))) g.null_on_empty = (strcmp(e, "null") == 0);
         if ((e = getenv("RHJ_FORCE_HBM_TABLE"))) g.force_hbm = atoi(e);
@@ -552,6 +553,11 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
     pa.meta = (BucketMeta *)g.meta.p; pa.summary = (PlanSummary *)g.summary.p;
     pa.lds_cap = lds_cap; pa.lds_max_slots = lds_max_slots; pa.build_chunk = build_chunk;
     pa.parent_mask = 0; pa.parent_flip = nullptr; pa.zero = nullptr; pa.zero_words = 0;
+    const bool sliced = ranged && (g.slice_skip != 0 || g.slice_end != 0);
+    if (sliced) {
+        if (g.slice_skip) { pa.slice_b0 = g.range_lo; pa.slice_o0 = g.slice_skip; }
+        if (g.slice_end) { pa.slice_b1 = g.range_lo + g.range_span - 1u; pa.slice_o1 = g.slice_end; }
+    }
     // probe tuples per fused unit: whole buckets when there are plenty of them, smaller spans (each unit
     // rebuilds its bucket's index) when a low radix would otherwise leave most CUs idle
     uint32_t fused_span = FJ_SPAN;
@@ -747,7 +753,9 @@ int join_device_once(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint
             // (A buffer below the relation's size is no obstacle: pairs beyond it are dropped as on every path and the caller hears
             // the count.  A rank's share of a sharded join — rhj_join_device_range — has a buffer for its share and buckets of the
             // whole join's size: the per-bucket rule is the same.)
-            bool try_spec = attempt == 0 && maybe_narrow && out != nullptr && g.no_spec <= 0 && !g.ablate &&
+            // (Not on a slice: a bucket cut between two devices has units that start inside it, and the last workgroup's check
+            // adds up to the whole relation.)
+            bool try_spec = attempt == 0 && maybe_narrow && out != nullptr && g.no_spec <= 0 && !g.ablate && !sliced &&
                             (nS >= nR ? nS : nR) / bins >= 4096;     // (units of 2.4 K tuples: 10M x 10M at 12 bits lost 7 % to its per-unit extras)
             if (try_spec && g.spec_score <= 0 && g.no_spec >= 0 && ++g.spec_skipped < 16) try_spec = false;   // (RHJ_NO_SPEC=-1: always try — to time a failing one)
             fa.spec = try_spec ? (nS >= nR ? 1u : 2u) : 0u;
@@ -1207,7 +1215,8 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
 
 // (on the calling thread's context, without the API lock: the public entry below, and the per-device workers of a multi-device join)
 static int join_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, uint32_t bucket_lo, uint32_t bucket_hi,
-                      rhj_result_tuple *d_out, uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches)
+                      rhj_result_tuple *d_out, uint64_t out_capacity, bool use_ctx_out, rhj_result_tuple **ctx_out, uint64_t *matches,
+                      uint64_t first_skip = 0, uint64_t last_end = 0)
 {
     if (matches) *matches = 0;
     if (ctx_out) *ctx_out = nullptr;
@@ -1216,11 +1225,12 @@ static int join_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, u
     if (bucket_hi > bins) bucket_hi = bins;
     if (bucket_lo >= bucket_hi) return 0;                     // an empty range joins nothing
     uint64_t m = 0;
-    const bool whole = bucket_lo == 0 && bucket_hi == bins;
+    const bool whole = bucket_lo == 0 && bucket_hi == bins && !first_skip && !last_end;
     g.range_lo = bucket_lo;
     g.range_span = whole ? 0u : bucket_hi - bucket_lo;        // the whole radix is the ordinary join (small path and all)
+    g.slice_skip = first_skip; g.slice_end = last_end;
     const int rc = join_device(d_R, nR, d_S, nS, d_out, out_capacity, use_ctx_out, ctx_out, &m);
-    g.range_lo = 0; g.range_span = 0;
+    g.range_lo = 0; g.range_span = 0; g.slice_skip = 0; g.slice_end = 0;
     if (matches) *matches = m;
     return rc;
 }
@@ -1428,6 +1438,19 @@ int rhj_join_device_range(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_
     return join_range(d_R, nR, d_S, nS, bucket_lo, bucket_hi, d_out, out_capacity, false, nullptr, matches);
 }
 
+/* A share cut INSIDE buckets (a hot bucket joined by several devices): the buckets [bucket_lo, bucket_hi) as above, but of the
+ * first one only the probe tuples from first_skip on take part and of the last one (bucket_hi - 1) only those before last_end
+ * (0: all of them) — positions among the tuples of the bucket's probe side (R when |R_b| >= |S_b|, rhjoin.c:86) in partition
+ * order; the build side of a cut bucket is whole on every device that has a piece of it.  The result is the canonical list's
+ * pairs of exactly those probe tuples (rhjoin.c:141-217 walks a bucket's probe tuples in order), so shares that tile the
+ * (bucket, probe position) space concatenate to the canonical result. */
+int rhj_join_device_slice(const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS, uint32_t bucket_lo, uint32_t bucket_hi,
+                          uint64_t first_skip, uint64_t last_end, rhj_result_tuple *d_out, uint64_t out_capacity, uint64_t *matches)
+{
+    RhjApiLock api_lock;
+    return join_range(d_R, nR, d_S, nS, bucket_lo, bucket_hi, d_out, out_capacity, false, nullptr, matches, first_skip, last_end);
+}
+
 int rhj_set_devices(int n) { RhjApiLock api_lock; g_ndev_env = 0; return set_devices(n); }
 /* Contiguous bucket ranges for n devices balanced by histR + histS (skewed keys): cuts[d] .. cuts[d + 1] is device d's range.
  * shard.bucket_ranges in C: the first bucket at which the running total reaches d / n of all tuples; no device needed. */
@@ -1448,7 +1471,49 @@ int rhj_plan_device_ranges(const uint64_t *histR, const uint64_t *histS, int bit
     cuts[n] = bins;
     return 0;
 }
-void rhj_set_devices_balance(int by_histogram) { RhjApiLock api_lock; g_balance = by_histogram != 0; }
+/* The same with cuts INSIDE hot buckets: device d joins from (cut_bucket[d], cut_off[d]) up to (cut_bucket[d + 1], cut_off[d + 1])
+ * in (bucket, probe position) order — rhj_cut_to_slice turns two neighbouring cuts into rhj_join_device_slice's arguments.  A cut
+ * falls inside a bucket only when that bucket holds at least 1 / (2 n) of all tuples and both relations have tuples in it: the
+ * device in front takes the bucket's build side and the probe tuples up to the cut (a multiple of 256), so that its tuples reach
+ * d / n of the total; every other cut is the range planner's bucket boundary.  shard.bucket_slices in C (integer arithmetic). */
+int rhj_plan_device_slices(const uint64_t *histR, const uint64_t *histS, int bits, int n, uint32_t *cut_bucket, uint64_t *cut_off)
+{
+    if (bits < 1 || bits > MAX_BITS || n < 1 || n > MAX_DEVICES) return -1;
+    const uint32_t bins = 1u << bits;
+    unsigned __int128 total = 0;
+    for (uint32_t b = 0; b < bins; ++b) total += (unsigned __int128)histR[b] + histS[b];
+    cut_bucket[0] = 0; cut_off[0] = 0;
+    uint32_t at = 0;
+    unsigned __int128 cum = 0;                         // tuples in front of bucket `at`
+    for (int d = 1; d < n; ++d) {
+        const unsigned __int128 target = total * (unsigned)d / (unsigned)n;
+        while (at < bins && cum + histR[at] + histS[at] <= target) { cum += (unsigned __int128)histR[at] + histS[at]; ++at; }
+        cut_bucket[d] = at; cut_off[d] = 0;            // (all buckets in front of `at` end at or before the target)
+        if (at == bins) continue;
+        const uint64_t hR = histR[at], hS = histS[at];
+        const unsigned __int128 w = (unsigned __int128)hR + hS;
+        const bool hot = hR != 0 && hS != 0 && w * 2u * (unsigned)n >= total;
+        if (!hot) {
+            if (cum < target) { cum += w; ++at; cut_bucket[d] = at; }      // the first boundary at or behind the target
+            continue;
+        }
+        const uint64_t pc = hR >= hS ? hR : hS, bc = hR >= hS ? hS : hR;
+        uint64_t off = target > cum + bc ? (uint64_t)(target - cum - bc) : 0u;
+        off &= ~(uint64_t)255;
+        if (off >= pc) { cum += w; ++at; cut_bucket[d] = at; }
+        else cut_off[d] = off;
+    }
+    cut_bucket[n] = bins; cut_off[n] = 0;
+    return 0;
+}
+/* cuts d and d + 1 of rhj_plan_device_slices -> the arguments of rhj_join_device_slice */
+void rhj_cut_to_slice(uint32_t b0, uint64_t o0, uint32_t b1, uint64_t o1, uint32_t *bucket_lo, uint32_t *bucket_hi, uint64_t *first_skip,
+                      uint64_t *last_end)
+{
+    *bucket_lo = b0; *first_skip = o0;
+    if (o1) { *bucket_hi = b1 + 1u; *last_end = o1; } else { *bucket_hi = b1; *last_end = 0; }
+}
+void rhj_set_devices_balance(int mode) { RhjApiLock api_lock; g_balance = mode < 0 ? 0 : mode > 2 ? 2 : mode; }
 
 /* the bucket range device d of n joins at `bits` radix bits (no device needed: the planning half of rhj_join_devices) */
 int rhj_device_range(int bits, int n, int d, uint32_t *lo, uint32_t *hi)
@@ -1474,6 +1539,7 @@ int rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *
     const int bits = g_all[0].bits;
     const uint32_t bins = 1u << bits;
     uint32_t cuts[MAX_DEVICES + 1];
+    uint64_t offs[MAX_DEVICES + 1] = {0};
     for (int d = 0; d <= n; ++d) cuts[d] = range_cut(bins, n, d);
     if (g_balance && n > 1 && nR && nS) {
         // skewed keys: the library's own device counts both relations' buckets (two launches, one read-back of 2^bits words each)
@@ -1483,13 +1549,17 @@ int rhj_join_devices(const rhj_tuple *const *d_R, uint64_t nR, const rhj_tuple *
         if (rhj_bucket_histogram_device(d_R[0], nR, d_h) || rhj_bucket_histogram_device(d_S[0], nS, d_h + bins)) return -1;
         HIP_TRY(hipMemcpyAsync(h.data(), d_h, (size_t)2 * bins * 8, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        if (rhj_plan_device_ranges(h.data(), h.data() + bins, bits, n, cuts)) return -1;
+        if (g_balance == 2 ? rhj_plan_device_slices(h.data(), h.data() + bins, bits, n, cuts, offs)
+                           : rhj_plan_device_ranges(h.data(), h.data() + bins, bits, n, cuts)) return -1;
     }
     int rcs[MAX_DEVICES];
     for (int d = 0; d < MAX_DEVICES; ++d) rcs[d] = -1;
     try {
         on_devices(n, [&](int d) {
-            rcs[d] = join_range(d_R[d], nR, d_S[d], nS, cuts[d], cuts[d + 1], out[d], capacity[d], false, nullptr, &matches[d]);
+            uint32_t lo, hi;
+            uint64_t skip, end;
+            rhj_cut_to_slice(cuts[d], offs[d], cuts[d + 1], offs[d + 1], &lo, &hi, &skip, &end);
+            rcs[d] = join_range(d_R[d], nR, d_S[d], nS, lo, hi, out[d], capacity[d], false, nullptr, &matches[d], skip, end);
         });
     } catch (...) { return -1; }
     int rc = 0;

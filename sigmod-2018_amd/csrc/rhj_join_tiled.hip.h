@@ -29,7 +29,18 @@ struct PlanArgs {
     const uint8_t  *parent_flip;
     uint32_t       *zero;           // words the plan clears for the kernels behind it (the fused join's ticket and status words), or null
     uint32_t        zero_words;
+    // rhj_join_device_slice (a hot bucket shared by several devices): of bucket slice_b0 only the probe tuples from slice_o0 on
+    // get units, of bucket slice_b1 only those before slice_o1 (0: all of them); 0xffffffff: no such bucket
+    uint32_t        slice_b0 = 0xffffffffu, slice_b1 = 0xffffffffu;
+    uint64_t        slice_o0 = 0, slice_o1 = 0;
 };
+
+// the probe tuples [lo, hi) of bucket b that this join takes (all of them unless the join is a slice; lo >= hi: none)
+__device__ __forceinline__ void plan_probe_span(const PlanArgs &a, uint32_t b, uint64_t pc, uint64_t &lo, uint64_t &hi)
+{
+    lo = b == a.slice_b0 ? a.slice_o0 : 0u;
+    hi = b == a.slice_b1 && a.slice_o1 != 0u ? min(a.slice_o1, pc) : pc;
+}
 
 constexpr uint32_t T32_PAD = 8;         // replica of the first 8 entries behind every 32-bit table
 
@@ -71,8 +82,11 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
         if (cR == 0 || cS == 0) continue;
         const bool flip = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;   // rhjoin.c:86 (>=)
         const uint64_t pc = flip ? cS : cR, bc = flip ? cR : cS;
+        uint64_t o_lo, o_hi;
+        plan_probe_span(a, b, pc, o_lo, o_hi);
+        if (o_lo >= o_hi) continue;                                        // (a slice that leaves nothing of this bucket)
         const uint64_t span = bc <= a.lds_cap ? a.span_lds : PR_UNIT;
-        nu += ((uint32_t)pc - 1u) / (uint32_t)span + 1u;                   // (bucket sizes are in [1, 2^32): 32-bit divisions)
+        nu += ((uint32_t)(o_hi - o_lo) - 1u) / (uint32_t)span + 1u;        // (bucket sizes are in [1, 2^32): 32-bit divisions)
         max_build = max(max_build, (uint32_t)min(bc, (uint64_t)0xffffffffu));
         if (bc <= a.lds_cap) {
             const uint32_t s = lds_slots_for(bc, a.lds_max_slots);
@@ -114,7 +128,12 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
         if (b >= b1) break;
         const uint64_t cR = cRv[i], cS = cSv[i];
         BucketMeta m = {0, 0, 0};
+        uint64_t o_lo = 0, o_hi = 0;
         if (cR != 0 && cS != 0) {
+            const bool flip0 = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;
+            plan_probe_span(a, b, flip0 ? cS : cR, o_lo, o_hi);
+        }
+        if (o_lo < o_hi) {
             const bool flip = a.parent_flip ? a.parent_flip[b & a.parent_mask] != 0 : cR < cS;
             const uint64_t pc = flip ? cS : cR, bc = flip ? cR : cS;
             if (bc <= a.lds_cap) {
@@ -135,8 +154,9 @@ __device__ __forceinline__ void plan_body(const PlanArgs &a, int bits, uint64_t 
                 }
             }
             const uint64_t span = bc <= a.lds_cap ? a.span_lds : PR_UNIT;
-            for (uint64_t o = 0; o < pc; o += span) {
-                Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min(span, pc - o);
+            (void)pc;
+            for (uint64_t o = o_lo; o < o_hi; o += span) {
+                Unit u; u.off = o; u.bucket = b; u.count = (uint32_t)min(span, o_hi - o);
                 a.units[ubase++] = u;
             }
         }

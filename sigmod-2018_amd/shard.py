@@ -60,6 +60,48 @@ def bucket_ranges(hist_r, hist_s, world):
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def bucket_slices(hist_r, hist_s, world):
+    """Shares (lo, hi, first_skip, last_end) per rank that may be cut INSIDE a hot bucket (a hot bucket's probe side
+    across GPUs, its build side replicated): rank r joins the buckets [lo, hi), of the first only the probe tuples from first_skip
+    on, of the last only those before last_end (0: all) — `rhj_join_device_slice`.  A cut falls inside a bucket only when the
+    bucket holds at least 1 / (2 world) of all tuples and both relations have tuples in it: the rank in front takes the build side
+    and the probe tuples up to the cut (a multiple of 256) so that its tuples reach r / world of the total; every other cut is a
+    bucket boundary.  `rhj_plan_device_slices` + `rhj_cut_to_slice` in Python, integer arithmetic (the two agree bit for bit)."""
+    hr = [int(x) for x in np.asarray(hist_r).tolist()]
+    hs = [int(x) for x in np.asarray(hist_s).tolist()]
+    bins = len(hr)
+    total = sum(hr) + sum(hs)
+    cuts = [(0, 0)]
+    at, cum = 0, 0
+    for d in range(1, world):
+        target = total * d // world
+        while at < bins and cum + hr[at] + hs[at] <= target:
+            cum += hr[at] + hs[at]
+            at += 1
+        cut = (at, 0)
+        if at < bins:
+            w = hr[at] + hs[at]
+            if hr[at] and hs[at] and w * 2 * world >= total:
+                pc, bc = max(hr[at], hs[at]), min(hr[at], hs[at])
+                off = (target - cum - bc if target > cum + bc else 0) & ~255
+                if off >= pc:
+                    cum += w
+                    at += 1
+                    cut = (at, 0)
+                else:
+                    cut = (at, off)
+            elif cum < target:
+                cum += w
+                at += 1
+                cut = (at, 0)
+        cuts.append(cut)
+    cuts.append((bins, 0))
+    out = []
+    for (b0, o0), (b1, o1) in zip(cuts, cuts[1:]):
+        out.append((b0, b1 + 1, o0, o1) if o1 else (b0, b1, o0, 0))
+    return out
+
+
 # ------------------------------------------------------------------ device steps on a GPU
 
 class RhjOps:
@@ -94,6 +136,8 @@ class RhjOps:
         """the canonical pair list of R x S — of the buckets [lo, hi) only when a range is given (rhj_join_device_range: the
         join's own first partition pass drops the other buckets; no selection pass, one read of each relation)"""
         self.rhj.set_bits(bits)
+        if bucket_range is not None and len(bucket_range) == 4 and not bucket_range[2] and not bucket_range[3]:
+            bucket_range = bucket_range[:2]
         if R.shape[0] == 0 or S.shape[0] == 0 or (bucket_range is not None and bucket_range[0] >= bucket_range[1]):
             return self.torch.empty((0, 2), dtype=self.torch.int64, device=R.device)
         if self.rhj.lib.rhj_get_order():
@@ -159,19 +203,19 @@ def sharded_join(ops, R, S, bits, group=None, gather=True, balance="equal"):
     exchanged so that every rank holds the canonical result.
     balance = "equal": ranges of equal width, no histogram, no host round trip (the default: at one rank the call IS the
     plain join); "hist": ranges balanced by histR + histS (skewed keys) — two histogram launches and a 2^bits-word
-    read-back in front of the join.
+    read-back in front of the join; "slice": the same, and a bucket that holds 1 / (2 world) of the tuples or more is shared by
+    the ranks around the cut (`bucket_slices`: its probe side split, its build side on each of them).
     Returns (pairs, info): pairs = canonical result (gather) or this rank's slice of it."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if balance == "hist" and world > 1:
+    if balance in ("hist", "slice") and world > 1:
         hr_h, hs_h = ops.histogram(R, bits).cpu().numpy(), ops.histogram(S, bits).cpu().numpy()
-        ranges = bucket_ranges(hr_h, hs_h, world)
+        ranges = bucket_slices(hr_h, hs_h, world) if balance == "slice" else bucket_ranges(hr_h, hs_h, world)
     else:
         ranges = equal_ranges(bits, world)
-    lo, hi = ranges[rank]
-    local = ops.join(R, S, bits, None if world == 1 else (lo, hi))
-    info = {"range": (lo, hi), "ranges": ranges, "local_pairs": int(local.shape[0])}
+    local = ops.join(R, S, bits, None if world == 1 else ranges[rank])
+    info = {"range": ranges[rank], "ranges": ranges, "local_pairs": int(local.shape[0])}
     if not gather or not dist.is_initialized():
         info["counts"] = [int(local.shape[0])]
         return local, info

@@ -28,6 +28,20 @@ class OracleOps:
         """bucket_range = (lo, hi): the canonical result restricted to those buckets — what rhj_join_device_range returns:
         here the oracle's join of the stable selections (bucket b of R only meets bucket b of S, rhjoin.c:42-57)"""
         self.calls["join"] += 1
+        skip = end = 0
+        if bucket_range is not None and len(bucket_range) == 4:
+            # a share cut inside its first / last bucket (rhj_join_device_slice): the ranged result without the pairs of the first
+            # bucket's probe tuples in front of `skip` and of the last bucket's from `end` on (a bucket's pairs follow its probe
+            # tuples in partition order, rhjoin.c:141-217; the probe side is R when |R_b| >= |S_b|, rhjoin.c:86)
+            skip, end = int(bucket_range[2]), int(bucket_range[3])
+            bucket_range = bucket_range[:2]
+            whole = self.join(R, S, bits, bucket_range)
+            self.calls["join"] -= 1
+            lo, hi = bucket_range
+            n_first, drop = self._pairs_before(R, S, bits, lo, skip) if skip else (0, 0)
+            n_last, keep = self._pairs_before(R, S, bits, hi - 1, end) if end else (0, 0)
+            a, b = drop, whole.shape[0] - ((n_last - keep) if end else 0)
+            return whole[a:max(a, b)]
         if bucket_range is not None:
             lo, hi = bucket_range
             bR, bS = R[:, 0] & ((1 << bits) - 1), S[:, 0] & ((1 << bits) - 1)
@@ -38,3 +52,19 @@ class OracleOps:
             return torch.empty((0, 2), dtype=torch.int64)
         p = self.o.join(ra, rb, bits)
         return torch.from_numpy(p.view(np.uint64).reshape(-1, 2).astype(np.int64))
+
+    @staticmethod
+    def _pairs_before(R, S, bits, b, pos):
+        """(pairs of bucket b, pairs of its probe tuples in front of position `pos`)"""
+        mask = (1 << bits) - 1
+        kR = R[:, 0].numpy().view(np.uint64)
+        kS = S[:, 0].numpy().view(np.uint64)
+        kR, kS = kR[(kR & np.uint64(mask)) == np.uint64(b)], kS[(kS & np.uint64(mask)) == np.uint64(b)]
+        probe, build = (kR, kS) if len(kR) >= len(kS) else (kS, kR)
+        if len(probe) == 0 or len(build) == 0:
+            return 0, 0
+        u, cnt = np.unique(build, return_counts=True)
+        at = np.searchsorted(u, probe)
+        at[at >= len(u)] = len(u) - 1
+        c = np.where(u[at] == probe, cnt[at], 0)
+        return int(c.sum()), int(c[:pos].sum())

@@ -96,6 +96,18 @@ for bits in (4, 8, 11):
     for d, part in enumerate(parts):
         b = np.array([keyR[int(x)] for x in part["row_idR"][:3000]], dtype=np.uint64) & mask
         assert ((b >= cuts[d]) & (b < cuts[d + 1])).all()
+    # (5) a key that dominates: the plan may cut INSIDE its bucket (balance mode 2: where a device's share ends inside it, the devices
+    # around the cut share its probe side; tests/test_gpu_shard.py cuts it for certain)
+    hotS = S.copy(); hotS["value"][: len(hotS) * 6 // 10] = R["value"][7]
+    dH = rhj.to_device(hotS)
+    wanth = o.join(R, hotS, bits)
+    caph = len(wanth) + 16
+    outh = [torch.empty((caph, 2), dtype=torch.int64, device=rhj.dev) for _ in range(n)]
+    ph = (C.c_void_p * n)(*[dH.data_ptr()] * n); poh = (C.c_void_p * n)(*[t.data_ptr() for t in outh]); capsh = (C.c_uint64 * n)(*[caph] * n)
+    lib.rhj_set_devices_balance(2)
+    assert lib.rhj_join_devices(pr, len(R), ph, len(hotS), poh, capsh, ms) == 0
+    parth = [rhj.pairs_to_numpy(t)[:int(m)] for t, m in zip(outh, ms)]
+    assert sum(int(m) for m in ms) == len(wanth) and (np.concatenate(parth) == wanth).all(), ("sliced", bits)
     lib.rhj_set_devices_balance(0)
     # a list that does not fit its device's buffer: the count comes back, rc 1
     caps2 = (C.c_uint64 * n)(*[10] * n)

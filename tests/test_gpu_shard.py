@@ -196,3 +196,47 @@ def test_small_workload_joins_as_independent_joins_of_a_plan(rhj, shard, oracle,
     own8 = shard.assign_joins(sizes, 8)
     load = [sum(s for s, o in zip(sizes, own8) if o == r) for r in range(8)]
     assert sorted(set(own8)) == list(range(8)) and max(load) - min(load) <= max(sizes)
+
+
+@pytest.mark.parametrize("bits,nR,nS,kind", [(4, 200_000, 300_000, "hot"), (8, 400_000, 400_000, "dup"), (12, 3_000_000, 3_000_000, "fk"),
+                                             (10, 500_000, 800_000, "hbm"), (14, 2_000_000, 6_000_000, "hot")])
+def test_shares_cut_inside_buckets_tile_the_plain_result(rhj, shard, oracle, bits, nR, nS, kind):
+    """rhj_join_device_slice (a hot bucket's probe side across GPUs, its build side on each): shares that tile the
+    (bucket, position among the bucket's probe tuples) space concatenate to the plain join's list, bit for bit — cuts planned by
+    shard.bucket_slices for 2, 3 and 5 ranks and cuts at arbitrary positions of arbitrary buckets; one-pass and two-pass
+    partitions, the fused kernels with split units, the tiled path (HBM tables), keys repeated on both sides."""
+    import torch
+    rng = np.random.default_rng(bits * 1000 + nR % 977)
+    R = oracle.generate(nR, 4 if kind == "dup" else 0, nR // 3, 0.0, 21)
+    S = oracle.generate(nS, 2 if kind == "dup" else 1, nR // 3 if kind == "dup" else nR, 0.7, 22)
+    if kind == "hot":
+        S["value"][rng.integers(0, nS, nS * 6 // 10)] = R["value"][5]          # one key holds 45 % of S
+    rhj.set_bits(bits)
+    rhj.lib.rhj_set_force_hbm_table(1 if kind == "hbm" else 0)
+    try:
+        dR, dS = rhj.to_device(R), rhj.to_device(S)
+        plain, m = rhj.join_device(dR, dS)
+        if nR + nS <= 1_000_000:
+            assert np.array_equal(rhj.pairs_to_numpy(plain), oracle.join(R, S, bits))
+        mask = np.uint64((1 << bits) - 1)
+        hr = np.bincount((R["value"] & mask).astype(np.int64), minlength=1 << bits)
+        hs = np.bincount((S["value"] & mask).astype(np.int64), minlength=1 << bits)
+        plans = [shard.bucket_slices(hr, hs, w) for w in (2, 3, 5)]
+        if kind == "hot":
+            assert all(any(s_[2] or s_[3] for s_ in p) for p in plans)          # the hot bucket IS cut
+        # arbitrary cuts: (bucket, position) pairs in order, positions anywhere inside the bucket's probe side (also beyond it)
+        cuts = sorted((int(b), int(rng.integers(0, max(hr[b], hs[b]) + 300))) for b in rng.integers(0, 1 << bits, 4))
+        cuts = [(0, 0)] + cuts + [(1 << bits, 0)]
+        plans.append([(b0, b1 + 1, o0, o1) if o1 else (b0, b1, o0, 0) for (b0, o0), (b1, o1) in zip(cuts, cuts[1:])])
+        for plan in plans:
+            parts = []
+            for lo, hi, skip, end in plan:
+                if lo >= hi:
+                    continue
+                t, k = rhj.join_device(dR, dS, bucket_range=(lo, hi, skip, end))
+                assert rhj.lib.rhj_last_spec() != 1                             # (never the speculation on a cut bucket)
+                parts.append(t[:k])
+            got = torch.cat(parts) if parts else plain[:0]
+            assert got.shape[0] == m and torch.equal(got, plain[:m]), (bits, kind, plan)
+    finally:
+        rhj.lib.rhj_set_force_hbm_table(0)

@@ -113,6 +113,32 @@ def test_device_ranges_are_the_sharding_modules_equal_ranges(lib):
                 cuts = (C.c_uint32 * (n + 1))()
                 assert lib.rhj_plan_device_ranges(hr.ctypes.data_as(C.POINTER(C.c_uint64)), hs.ctypes.data_as(C.POINTER(C.c_uint64)), bits, n, cuts) == 0
                 assert [(cuts[d], cuts[d + 1]) for d in range(n)] == [(int(a), int(b)) for a, b in shard.bucket_ranges(hr, hs, n)], (bits, n)
+    # the plan that may cut INSIDE a hot bucket against shard.bucket_slices: one dominant bucket, two, Zipf-like, uniform, empty
+    for bits in (1, 4, 8, 12):
+        bins = 1 << bits
+        hot1 = np.vstack([np.full(bins, 1000, dtype=np.int64), np.full(bins, 1000, dtype=np.int64)]); hot1[1, bins // 3] = 5_000_000
+        hot2 = hot1.copy(); hot2[0, bins - 1] = 3_000_000; hot2[1, bins - 1] = 2_999_999
+        for hist in (hot1, hot2, rng.zipf(1.2, (2, bins)) % 10**7, rng.integers(0, 1000, (2, bins)), np.zeros((2, bins), dtype=np.int64),
+                     np.vstack([np.eye(1, bins, 0, dtype=np.int64)[0] * 10**9, np.eye(1, bins, 0, dtype=np.int64)[0] * 7])):
+            hr, hs = (np.ascontiguousarray(h, dtype=np.uint64) for h in hist)
+            for n in range(1, 9):
+                cb, co = (C.c_uint32 * (n + 1))(), (C.c_uint64 * (n + 1))()
+                assert lib.rhj_plan_device_slices(hr.ctypes.data_as(C.POINTER(C.c_uint64)), hs.ctypes.data_as(C.POINTER(C.c_uint64)), bits, n, cb, co) == 0
+                cuts = [(cb[d], co[d]) for d in range(n + 1)]
+                assert cuts[0] == (0, 0) and cuts[-1] == (bins, 0) and cuts == sorted(cuts), (bits, n, cuts)
+                got = []
+                for d in range(n):
+                    skip, end = C.c_uint64(0), C.c_uint64(0)
+                    lib.rhj_cut_to_slice(cb[d], co[d], cb[d + 1], co[d + 1], C.byref(lo), C.byref(hi), C.byref(skip), C.byref(end))
+                    got.append((lo.value, hi.value, skip.value, end.value))
+                assert got == shard.bucket_slices(hr, hs, n), (bits, n)
+                for b, off in cuts:                                  # a cut inside a bucket: a hot one, in front of its last probe tuple
+                    if off:
+                        w, tot = int(hr[b]) + int(hs[b]), int(hr.sum()) + int(hs.sum())
+                        assert off % 256 == 0 and off < max(int(hr[b]), int(hs[b])) and w * 2 * n >= tot and hr[b] and hs[b]
+            if hist is hot1 and bits >= 4:                           # the dominant bucket is shared: no device gets more than ~2 / n
+                sl = shard.bucket_slices(hr, hs, 4)
+                assert sum(1 for s_ in sl if s_[2] or s_[3]) >= 2
     assert lib.rhj_device_range(4, 9, 0, C.byref(lo), C.byref(hi)) == -1       # at most eight devices
     assert lib.rhj_device_range(4, 2, 2, C.byref(lo), C.byref(hi)) == -1
     assert lib.rhj_device_range(16, 2, 0, C.byref(lo), C.byref(hi)) == -1

@@ -57,6 +57,17 @@ def _worker(rank, world, port, bits, out_q):
     # (1b) ranges balanced by histR + histS (Zipf keys): two histograms in front, same canonical result
     fullh, infoh = shard.sharded_join(ops, tR, tS, bits, balance="hist")
     ok1 = ok1 and bool((as_pairs(fullh) == want).all()) and ops.calls == {"histogram": 2, "select": 0, "join": 2}
+    # (1c) a key that dominates (60 % of S): the cut falls INSIDE its bucket — the bucket's probe side is shared by the two ranks,
+    # its build side on both (bucket_slices, rhj_join_device_slice) — same canonical result
+    hotS = S.copy()
+    hotS["value"][: len(hotS) * 6 // 10] = R["value"][len(R) // 3]
+    thS = torch.from_numpy(hotS.view(np.int64).reshape(-1, 2).copy())
+    fulls, infos = shard.sharded_join(ops, tR, thS, bits, balance="slice")
+    wants = o.join(R, hotS, bits)
+    gots = as_pairs(fulls)
+    ok1 = ok1 and len(gots) == len(wants) and bool((gots == wants).all()) and ops.calls == {"histogram": 4, "select": 0, "join": 3}
+    ok1 = ok1 and any(len(r) == 4 and (r[2] or r[3]) for r in infos["ranges"]) and min(infos["counts"]) * 4 > max(infos["counts"])
+    ops.calls = {"histogram": 2, "select": 0, "join": 2}
     # (2) kept sharded (the consumer lives on this rank): this rank's slice only
     local, info2 = shard.sharded_join(ops, tR, tS, bits, gather=False)
     off = sum(info["counts"][:rank])
@@ -108,7 +119,7 @@ def test_bucket_range_sharding_and_allgatherv(bits):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
-    ranges = sorted(r[3] for r in res)
+    ranges = sorted(tuple(r[3])[:2] for r in res)
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 1 << bits
     assert all(c > 0 for c in res[0][2])              # both ranks contributed pairs
 
