@@ -31,7 +31,7 @@ struct RelArgs {                 // one relation through one partition pass
     uint32_t         parts;      // strips per group = ceil(group / strip)
     uint32_t         per;        // groups per scan slice = ceil(groups / FH_SLICES)
     uint32_t         strip;      // pass-1 tiles a strip (1..PT_STRIP: fewer for small relations, whose strips would not fill the chip)
-    uint32_t         pad;
+    uint32_t         range_bits; // the low key bits range_lo / range_span count in (0: this partition's whole radix; the low-radix path: the caller's bits)
     // pass 2's start offsets come in two parts: cnt[tile (d, j)][digit] = the tuples of (d, digit) in groups of j's slice in
     // front of j, sbase[d][slice][digit] = where that slice starts in the output (bucket start + the slices in front of it)
     uint32_t        *sbase;

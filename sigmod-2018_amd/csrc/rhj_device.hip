@@ -942,6 +942,7 @@ int join_device_lr(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *dS, uint64
     ps.r[0] = RelArgs{dR, (rhj_tuple *)g.partR.p, nullptr, nR, 0, 0, nullptr, nullptr};
     ps.r[1] = RelArgs{dS, (rhj_tuple *)g.partS.p, nullptr, nS, 0, 0, nullptr, nullptr};
     ps.tmp[0] = (rhj_tuple *)g.tmpR.p; ps.tmp[1] = (rhj_tuple *)g.tmpS.p;
+    for (int i = 0; i < 2; ++i) { ps.r[i].range_lo = g.range_lo; ps.r[i].range_span = g.range_span; ps.r[i].range_bits = (uint32_t)r; }   // (a share: the CALLER's buckets)
     ps.lo_bits = r;                                            // pass 1 on exactly the caller's bits: pass 2 reads in canonical order
     uint32_t *words = (uint32_t *)g.lr_words.p;                // word 0: a pass-2 tile / chunk beyond one batch; word 1: k_lr_emit's ticket
     uint8_t *parent_flip = (uint8_t *)(words + 16);            // [2 << r]
@@ -1110,7 +1111,9 @@ static int join_device_radix(const rhj_tuple *dR, uint64_t nR, const rhj_tuple *
     bool overflow = false;
     {
         // few radix bits over big inputs, canonical order wanted: run on finer buckets, emit in the caller's order
-        const int kb = (!g.no_lowradix && !g.no_fused && !g.force_hbm && !g.wide_row_ids && !g.range_span && nR < (1ull << 32) && nS < (1ull << 32))
+        // (also for a rank's share of a sharded join — the partition's first pass, on the caller's bits, drops the other buckets —
+        // but not for a share cut inside a bucket: that is a matter of the plan's units, and these are sub-buckets)
+        const int kb = (!g.no_lowradix && !g.no_fused && !g.force_hbm && !g.wide_row_ids && !g.slice_skip && !g.slice_end && nR < (1ull << 32) && nS < (1ull << 32))
                            ? lowradix_sub_bits(g.bits, nR, nS) : 0;
         if (kb) {
             if (ctx_init()) return -1;
@@ -1211,6 +1214,29 @@ int filter_eq2_device(const uint64_t *colA, const uint64_t *selA, const uint64_t
     g.stats.n_r = n; g.stats.matches = *hits;
     g.stats.ms_total = g.stats.ms_probe = stage_ms(ST_HIST, ST_END);
     return 0;
+}
+
+// stable selection of the tuples whose bucket lies in [bucket_lo, bucket_hi) (on the calling thread's context, no API lock)
+static int select_range(const rhj_tuple *d_in, uint64_t n, uint32_t bucket_lo, uint32_t bucket_hi, rhj_tuple *d_out, uint64_t capacity,
+                        uint64_t *count)
+{
+    if (ctx_init()) return -1;
+    *count = 0;
+    if (n == 0 || bucket_hi <= bucket_lo) return 0;
+    const uint32_t mask = (1u << g.bits) - 1u;
+    const uint64_t tiles = (n + SH_TILE - 1) / SH_TILE;
+    if (ensure(g.ftile, tiles * 8) || ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary))) return -1;
+    uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
+    RHJ_LAUNCH(k_select_count, dim3((unsigned)tiles), dim3(SH_BLOCK), 0, g.stream, d_in, n, mask, bucket_lo, bucket_hi,
+               (uint64_t *)g.ftile.p);
+    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
+    RHJ_LAUNCH(k_select_write, dim3((unsigned)tiles), dim3(SH_BLOCK), 0, g.stream, d_in, n, mask, bucket_lo, bucket_hi,
+               (const uint64_t *)g.fbase.p, d_out, capacity);
+    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *count = *(uint64_t *)g.pin;
+    return *count > capacity ? 1 : 0;
 }
 
 // (on the calling thread's context, without the API lock: the public entry below, and the per-device workers of a multi-device join)
@@ -1667,23 +1693,7 @@ int rhj_select_bucket_range_device(const rhj_tuple *d_in, uint64_t n, uint32_t b
                                    rhj_tuple *d_out, uint64_t capacity, uint64_t *count)
 {
     RhjApiLock api_lock;
-    if (ctx_init()) return -1;
-    *count = 0;
-    if (n == 0 || bucket_hi <= bucket_lo) return 0;
-    const uint32_t mask = (1u << g.bits) - 1u;
-    const uint64_t tiles = (n + SH_TILE - 1) / SH_TILE;
-    if (ensure(g.ftile, tiles * 8) || ensure(g.fbase, tiles * 8) || ensure(g.summary, sizeof(PlanSummary))) return -1;
-    uint64_t *total = &((PlanSummary *)g.summary.p)->matches;
-    RHJ_LAUNCH(k_select_count, dim3((unsigned)tiles), dim3(SH_BLOCK), 0, g.stream, d_in, n, mask, bucket_lo, bucket_hi,
-               (uint64_t *)g.ftile.p);
-    if (launch_offsets((const uint64_t *)g.ftile.p, (uint64_t *)g.fbase.p, nullptr, tiles, tiles, total)) return -1;
-    RHJ_LAUNCH(k_select_write, dim3((unsigned)tiles), dim3(SH_BLOCK), 0, g.stream, d_in, n, mask, bucket_lo, bucket_hi,
-               (const uint64_t *)g.fbase.p, d_out, capacity);
-    HIP_TRY(hipMemcpyAsync(g.pin, total, 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    *count = *(uint64_t *)g.pin;
-    return *count > capacity ? 1 : 0;
+    return select_range(d_in, n, bucket_lo, bucket_hi, d_out, capacity, count);
 }
 
 static void release_current()

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
     for (int k = 0; k < PT_V; ++k) {
         const uint64_t key = ((uint64_t)t[k].y << 32) | t[k].x;   // (a 32-bit form makes hipcc spill t[] to scratch:
         const uint32_t d = (uint32_t)(key >> shift) & mask;       //  shift is a run-time 0 for that reason)
-        if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << max(shift + bits, next_shift + next_bits)) - 1u)) - r.range_lo) < r.range_span;
+        if (RANGED) ok[k] = ok[k] && (((uint32_t)key & ((1u << (r.range_bits ? (int)r.range_bits : max(shift + bits, next_shift + next_bits))) - 1u)) - r.range_lo) < r.range_span;
         dig[k] = d;
         uint64_t peers = __ballot(ok[k]);               // rolled form: digit_peers() measured 6 % faster in the scatter
         for (int b = 0; b < bits; ++b) {                 // kernels but 3 % slower in this one, which sits on the HBM limit

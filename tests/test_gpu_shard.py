@@ -240,3 +240,34 @@ def test_shares_cut_inside_buckets_tile_the_plain_result(rhj, shard, oracle, bit
             assert got.shape[0] == m and torch.equal(got, plain[:m]), (bits, kind, plan)
     finally:
         rhj.lib.rhj_set_force_hbm_table(0)
+
+
+def test_a_few_bit_share_takes_the_low_radix_path(rhj, oracle):
+    """rhj_join_device_range on the reference's 4 radix bits over relations whose buckets are beyond the fused kernels' index: the
+    share runs the low-radix path like the whole join does — its first pass, on the caller's bits, drops the other
+    ranks' buckets — instead of HBM tables over build sides of hundreds of thousands of tuples.  The shares' lists concatenate to
+    the plain join's, bit for bit (uniform and repeated keys); a share cut inside a bucket is the plan's matter (tiled path)."""
+    import torch
+    n = 6_000_000
+    for kindR, kindS, dom in ((0, 1, n), (0, 1, n // 2)):
+        R = oracle.generate(n, kindR, dom, 0.0, 31)
+        S = oracle.generate(n + 1000, kindS, dom, 0.0, 32)
+        dR, dS = rhj.to_device(R), rhj.to_device(S)
+        rhj.set_bits(4)
+        plain, m = rhj.join_device(dR, dS)
+        assert rhj.stats()["path"] == "lowradix", rhj.stats()
+        parts = []
+        for lo, hi in ((0, 4), (4, 5), (5, 12), (12, 16)):
+            t, k = rhj.join_device(dR, dS, bucket_range=(lo, hi))
+            assert rhj.stats()["path"] == "lowradix", (lo, hi, rhj.stats())
+            parts.append(t[:k])
+        assert sum(p.shape[0] for p in parts) == m and torch.equal(torch.cat(parts), plain[:m])
+        t, k = rhj.join_device(dR, dS, bucket_range=(3, 9, 1000, 2000))       # cut inside buckets: the plan's matter
+        assert rhj.stats()["path"] != "lowradix" and k > 0
+        del dR, dS, plain, parts, t
+    for nr, ns, lr in ((200_000, 300_000, False), (700_000, 900_000, True)):   # against the oracle: a share the fused kernels take as it is, and a low-radix one
+        sR, sS = R[:nr], S[:ns]
+        t, k = rhj.join_device(rhj.to_device(sR), rhj.to_device(sS), bucket_range=(2, 7))
+        assert (rhj.stats()["path"] == "lowradix") == lr, (nr, rhj.stats())
+        inR, inS = ((x["value"] & np.uint64(15) >= 2) & (x["value"] & np.uint64(15) < 7) for x in (sR, sS))
+        assert np.array_equal(rhj.pairs_to_numpy(t[:k]), oracle.join(sR[inR], sS[inS], 4))
