@@ -148,6 +148,25 @@ template <bool N32> __device__ __forceinline__ uint4 pt_load(const rhj_tuple *ba
     if (N32) { const Tuple12 x = reinterpret_cast<const Tuple12 *>(base)[i]; return make_uint4(x.klo, x.khi, x.rid, 0u); }
     return reinterpret_cast<const uint4 *>(base)[i];
 }
+// A unit's probe tuples are read once: with the nt policy they leave the build sides' lines in the L2s alone — C3 probe stage
+// 1.893 -> 1.869 ms (gpurun_out/r04t/aux_abn.txt; through a descriptor: nt 1.885, sc1 1.909, nt sc1 1.867, sc0 sc1 1.899, sc0 nt
+// 1.879; the PAIR stores with nt: 1.908 -> 1.971, they lose the L2's write combining; the resident kernels — no gathers — gain
+// nothing: C4 5.38 -> 5.42, and keep the default policy).  -DFJ_PROBE_PLAIN: the default policy everywhere (A/B).
+template <bool N32> __device__ __forceinline__ uint4 pt_load_nt(const rhj_tuple *base, uint64_t i)
+{
+#ifndef FJ_PROBE_PLAIN
+    if (N32) {
+        const uint32_t *x = reinterpret_cast<const uint32_t *>(reinterpret_cast<const Tuple12 *>(base) + i);
+        return make_uint4(__builtin_nontemporal_load(x), __builtin_nontemporal_load(x + 1), __builtin_nontemporal_load(x + 2), 0u);
+    }
+#endif
+    return pt_load<N32>(base, i);
+}
+#ifdef FJ_OUT_NT
+#define FJ_STORE_PAIR(ptr, v) do { const uint4 v_ = (v); uint32_t *p_ = reinterpret_cast<uint32_t *>(ptr); __builtin_nontemporal_store(v_.x, p_); __builtin_nontemporal_store(v_.y, p_ + 1); __builtin_nontemporal_store(v_.z, p_ + 2); __builtin_nontemporal_store(v_.w, p_ + 3); } while (0)
+#else
+#define FJ_STORE_PAIR(ptr, v) (*(ptr) = (v))
+#endif
 template <bool N32> __device__ __forceinline__ uint2 pt_load_key(const rhj_tuple *base, uint64_t i)
 {
     if (N32) { const Tuple12 *x = reinterpret_cast<const Tuple12 *>(base) + i; return make_uint2(x->klo, x->khi); }
@@ -444,6 +463,18 @@ struct FjGather {
         }
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, 16 /* sc1 */);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    // the same descriptor for a STREAM (a unit's probe tuples), with the cache policy as a compile-time constant (1 sc0, 2 nt, 16 sc1)
+    template <int AUX> __device__ __forceinline__ uint4 stream(uint32_t pos) const
+    {
+        if (N32) {
+            typedef uint32_t v3 __attribute__((ext_vector_type(3)));
+            const v3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(pos * 12u), 0, AUX);
+            return make_uint4(v.x, v.y, v.z, 0u);
+        }
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, AUX);
         return make_uint4(v.x, v.y, v.z, v.w);
     }
 };
@@ -1088,7 +1119,7 @@ __device__ __forceinline__ void fj_emit_records(bool flip, const uint4 *rec, uin
 #pragma unroll
         for (int k = 1; k < V; ++k) { const uint32_t ok_ = __shfl(off[k], src, 64); if (kk == (uint32_t)k) o = ok_; }
         const uint64_t at = wbase + o + (r.z >> 8);
-        if (e < nrec && at < cap) out[at] = make_pair(flip, r.y, 0u, r.x, 0u);
+        if (e < nrec && at < cap) FJ_STORE_PAIR(&out[at], make_pair(flip, r.y, 0u, r.x, 0u));
     }
 }
 
@@ -1118,7 +1149,7 @@ __device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const uint64_t at = wbase + off[k];
-        if (c[k] != 0 && at < cap) out[at] = make_pair(flip, q[k].z, 0u, first[k], 0u);
+        if (c[k] != 0 && at < cap) FJ_STORE_PAIR(&out[at], make_pair(flip, q[k].z, 0u, first[k], 0u));
     }
     fj_emit_records(flip, rec, nrec, off, wbase, out, cap);
     return cs;
@@ -1226,6 +1257,10 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     uint2 *srow = reinterpret_cast<uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
     FjGather<N32> G;
     G.init(bdp, bpos, bc);
+#ifdef FJ_PROBE_AUX
+    FjGather<N32> PS;                                 // (A/B: the unit's probe tuples through a descriptor, policy FJ_PROBE_AUX)
+    PS.init(prp, ppos, un.count);
+#endif
     FjOvf O;                                          // double-buffered: the previous unit's emit may still be pending
     O.buf = f.ovf + ((size_t)blockIdx.x * 2 + (iter & 1u)) * FJ_OVF_CAP;
     O.table = f.ovf_base + ((size_t)blockIdx.x * 2 + (iter & 1u)) * (FJ_GROUPS * 16u);
@@ -1260,7 +1295,11 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
         for (int k = 0; k < FJ_V; ++k) {
             const uint32_t i = t0 + k * WAVE + lane;
             okk[k] = i < un.count;
-            q[k] = okk[k] ? pt_load<N32>(prp, ppos + i) : make_uint4(0, 0, 0, 0);
+#ifdef FJ_PROBE_AUX
+            q[k] = okk[k] ? PS.template stream<FJ_PROBE_AUX>(i) : make_uint4(0, 0, 0, 0);
+#else
+            q[k] = okk[k] ? (MAYRES ? pt_load<N32>(prp, ppos + i) : pt_load_nt<N32>(prp, ppos + i)) : make_uint4(0, 0, 0, 0);   // (nt: the gather kernels only)
+#endif
         }
         O.gid = grp;
         uint32_t run[FJ_V], bm[FJ_V];
@@ -1285,7 +1324,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
                     spec_bad = spec_bad || c[k] != 1u;
 #endif
                     const uint64_t at = spec_base + i;
-                    if (at < a.out_capacity) out[at] = make_pair(flip, q[k].z, N32 ? 0u : q[k].w, flo[k], fhi[k]);
+                    if (at < a.out_capacity) FJ_STORE_PAIR(&out[at], make_pair(flip, q[k].z, N32 ? 0u : q[k].w, flo[k], fhi[k]));
                 }
             }
             if (__ballot(spec_bad) != 0) {            // noticed at once, and by everybody
@@ -1560,6 +1599,10 @@ __device__ __forceinline__ void fj_walk_unit(const FusedArgs &f, uint32_t lds_by
     const uint2 *srow = reinterpret_cast<const uint2 *>(f.stash_row + (flip ? f.nR : 0) + ppos);
     FjGather<N32> G;
     G.init(bdp, bpos, bc);
+#ifdef FJ_PROBE_AUX
+    FjGather<N32> PS;                                 // (A/B: the unit's probe tuples through a descriptor, policy FJ_PROBE_AUX)
+    PS.init(prp, ppos, un.count);
+#endif
     __syncthreads();                                  // the previous unit's index is no longer read
     fj_build<RES, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(f.ovf + (size_t)blockIdx.x * 2 * FJ_OVF_CAP), wsum, sh_pick);
     __syncthreads();

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_local_part(RelArgs r0, RelArgs r1,
         const uint32_t i = w * (WAVE * PT_V) + k * WAVE + lane;
         ok[k] = i < count;
         if (COL) { if (ok[k]) { const uint2 kv = col[i]; t[k] = make_uint4(kv.x, kv.y, (uint32_t)(beg + i), (uint32_t)((beg + i) >> 32)); } }
-        else if (ok[k]) t[k] = in[i];
+        else if (ok[k]) t[k] = in[i];                 // (with the nt policy: C3 +1 %, at 14 bits +25 % — gpurun_out/r04t/nt2_*.txt)
     }
     __syncthreads();
 
