@@ -437,6 +437,9 @@ __device__ __forceinline__ void fj_build(const IX &X, const rhj_tuple *part, uin
 // sc1 (L1 bypass): a gathered line is used once per candidate, so allocating it in the 32 KiB
 // vector L1 only evicts the streamed probe data.  A/B on MI355X (tools/ab.py, fused kernel on
 // 100Mx100M@12): plain 4.64 ms, nt 4.06 ms, sc1 3.8 ms.
+#ifndef FJ_GATHER_AUX
+#define FJ_GATHER_AUX 16   /* sc1 */
+#endif
 template <bool N32>
 struct FjGather {
     __amdgpu_buffer_rsrc_t rsrc;
@@ -454,15 +457,15 @@ struct FjGather {
         if (N32) {
 #ifdef FJ_ABL_G8          // timing experiment only (wrong results): 8-byte gathers from a third less memory
             typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-            const v2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(pos * 8u), 0, 16 /* sc1 */);
+            const v2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(pos * 8u), 0, FJ_GATHER_AUX);
             return make_uint4(w.x, w.y, w.x, 0u);
 #endif
             typedef uint32_t v3 __attribute__((ext_vector_type(3)));
-            const v3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(pos * 12u), 0, 16 /* sc1 */);
+            const v3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(pos * 12u), 0, FJ_GATHER_AUX);
             return make_uint4(v.x, v.y, v.z, 0u);
         }
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-        const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, 16 /* sc1 */);
+        const v4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pos * 16u), 0, FJ_GATHER_AUX);
         return make_uint4(v.x, v.y, v.z, v.w);
     }
     // the same descriptor for a STREAM (a unit's probe tuples), with the cache policy as a compile-time constant (1 sc0, 2 nt, 16 sc1)
