@@ -1095,7 +1095,9 @@ __device__ __forceinline__ uint32_t fj_walk_group(const IX &X, const FjGather<N3
             const bool isrec = eq && cc != 0;
             const uint64_t mk = __ballot(isrec);
             const uint32_t slot = ne + (uint32_t)__popcll(mk & lt);
+#ifndef FJ_ABL_NOREC      // (timing experiment only, wrong results: second and later matches are found but leave no record and no pair)
             if (isrec && slot < FJ_REC_CAP) rec[slot] = make_uint4(g[j].z, pr[j], (ks[j] * WAVE + lane) | (cc << 8), 0u);
+#endif
             ne += (uint32_t)__popcll(mk);
             cannot = cannot || (eq && cc >= 65535u);   // (the ordinal has sixteen bits)
 #pragma unroll
@@ -1104,6 +1106,9 @@ __device__ __forceinline__ uint32_t fj_walk_group(const IX &X, const FjGather<N3
         }
     }
     cannot = cannot || ne > FJ_REC_CAP;
+#ifdef FJ_ABL_NOREC
+    return 0;
+#endif
     return min(ne, FJ_REC_CAP);
 }
 
