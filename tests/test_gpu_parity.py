@@ -673,3 +673,39 @@ print("BAD" if bad else "OK", bad)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and r.stdout.strip().startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+MSD_CHILD = r'''
+import importlib, sys
+import numpy as np
+sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+from pyoracle import Oracle, TUPLE
+o = Oracle()
+rhj = importlib.import_module("sigmod-2018_amd").RHJ(device=0)
+for bits in (9, 12, 13, 14, 15):
+    for n, kind, dom in ((4097, 4, 1 << 30), (700001, 1, 100000), (1200000, 2, 2000)):
+        rel = o.generate(n, kind, dom, 0.9, 500 + bits)
+        want, hist, psum = o.partition(rel, bits)
+        out, h, p = rhj.partition_device(rhj.to_device(rel), bits)
+        got = out.cpu().numpy().view(np.uint64).reshape(-1, 2).copy().view(TUPLE).reshape(-1)
+        assert (h == hist).all() and (p == psum).all() and (got == want).all(), (n, bits)
+    R, S = o.generate(600000, 0, 0, 0.0, 7), o.generate(900000, 2, 600000, 0.8, 8)
+    rhj.set_bits(bits)
+    t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S))
+    assert (rhj.pairs_to_numpy(t)[:m] == o.join(R, S, bits)).all(), bits
+    t, m = rhj.join_device(rhj.to_device(R), rhj.to_device(S), bucket_range=(3, (1 << bits) - 5))
+    sel = lambda x: x[((x["value"] & np.uint64((1 << bits) - 1)) >= 3) & ((x["value"] & np.uint64((1 << bits) - 1)) < (1 << bits) - 5)]
+    assert (rhj.pairs_to_numpy(t)[:m] == o.join(sel(R), sel(S), bits)).all(), ("ranged", bits)
+print("ok")
+'''
+
+
+def test_two_pass_partition_with_pass_1_on_the_high_bits():
+    """RHJ_MSD=1 (A/B knob, DESIGN.md 4.1): pass 1 of the two-pass partition takes the HIGH bits of the radix and pass 2 the low ones —
+    same buckets, same order inside them.  Partition, join and ranged join against the oracle at 9..15 bits, in a process of its
+    own (the knob is read when the library's context is made)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", MSD_CHILD], cwd=root, env=dict(os.environ, RHJ_MSD="1"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0 and b"ok" in res.stdout, res.stderr.decode()[-3000:]
