@@ -1500,8 +1500,9 @@ int rhj_plan_device_ranges(const uint64_t *histR, const uint64_t *histS, int bit
 /* The same with cuts INSIDE hot buckets: device d joins from (cut_bucket[d], cut_off[d]) up to (cut_bucket[d + 1], cut_off[d + 1])
  * in (bucket, probe position) order — rhj_cut_to_slice turns two neighbouring cuts into rhj_join_device_slice's arguments.  A cut
  * falls inside a bucket only when that bucket holds at least 1 / (2 n) of all tuples and both relations have tuples in it: the
- * device in front takes the bucket's build side and the probe tuples up to the cut (a multiple of 256), so that its tuples reach
- * d / n of the total; every other cut is the range planner's bucket boundary.  shard.bucket_slices in C (integer arithmetic). */
+ * device in front takes the bucket's build side and the probe tuples up to the cut (a multiple of 256; not a sliver: a cut that would
+ * leave less than an eighth of the probe side on one side goes to that boundary), so that its tuples reach d / n of the total; every
+ * other cut is the range planner's bucket boundary.  shard.bucket_slices in C (integer arithmetic). */
 int rhj_plan_device_slices(const uint64_t *histR, const uint64_t *histS, int bits, int n, uint32_t *cut_bucket, uint64_t *cut_off)
 {
     if (bits < 1 || bits > MAX_BITS || n < 1 || n > MAX_DEVICES) return -1;
@@ -1526,6 +1527,8 @@ int rhj_plan_device_slices(const uint64_t *histR, const uint64_t *histS, int bit
         const uint64_t pc = hR >= hS ? hR : hS, bc = hR >= hS ? hS : hR;
         uint64_t off = target > cum + bc ? (uint64_t)(target - cum - bc) : 0u;
         off &= ~(uint64_t)255;
+        if (off * 8u < pc) off = 0;                    // (a sliver of a bucket is not worth a second partition of its build side:
+        else if ((pc - off) * 8u < pc) off = pc;       //  less than an eighth of the probe side on either side goes to the boundary)
         if (off >= pc) { cum += w; ++at; cut_bucket[d] = at; }
         else cut_off[d] = off;
     }

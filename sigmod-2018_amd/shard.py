@@ -65,8 +65,8 @@ def bucket_slices(hist_r, hist_s, world):
     across GPUs, its build side replicated): rank r joins the buckets [lo, hi), of the first only the probe tuples from first_skip
     on, of the last only those before last_end (0: all) — `rhj_join_device_slice`.  A cut falls inside a bucket only when the
     bucket holds at least 1 / (2 world) of all tuples and both relations have tuples in it: the rank in front takes the build side
-    and the probe tuples up to the cut (a multiple of 256) so that its tuples reach r / world of the total; every other cut is a
-    bucket boundary.  `rhj_plan_device_slices` + `rhj_cut_to_slice` in Python, integer arithmetic (the two agree bit for bit)."""
+    and the probe tuples up to the cut (a multiple of 256, never a sliver of less than an eighth of the probe side) so that its
+    tuples reach r / world of the total; every other cut is a bucket boundary.  `rhj_plan_device_slices` + `rhj_cut_to_slice` in Python, integer arithmetic (the two agree bit for bit)."""
     hr = [int(x) for x in np.asarray(hist_r).tolist()]
     hs = [int(x) for x in np.asarray(hist_s).tolist()]
     bins = len(hr)
@@ -84,6 +84,10 @@ def bucket_slices(hist_r, hist_s, world):
             if hr[at] and hs[at] and w * 2 * world >= total:
                 pc, bc = max(hr[at], hs[at]), min(hr[at], hs[at])
                 off = (target - cum - bc if target > cum + bc else 0) & ~255
+                if off * 8 < pc:                     # (not a sliver: less than an eighth of the probe side on either side
+                    off = 0                          #  goes to the boundary — it would cost a second partition of the build side)
+                elif (pc - off) * 8 < pc:
+                    off = pc
                 if off >= pc:
                     cum += w
                     at += 1
