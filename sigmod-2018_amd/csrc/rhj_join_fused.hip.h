@@ -36,7 +36,7 @@ constexpr int FJ_BATCH = FJ_BLOCK * FJ_V;       // 4096 probe tuples per batch
 constexpr uint32_t FJ_SPAN = 65536;             // probe tuples per unit
 constexpr uint32_t FJ_LDS_EXTRA = 2048;         // bytes of LDS behind the table (static: the words below, the speculative kernel's group prefixes)
 constexpr uint32_t FJ_OVF_CAP = 32768;          // overflow entries per unit before it falls back to the index walk
-constexpr uint32_t FJ_REC_CAP = 512;                  // 16-byte records (second and later matches) of one 256-tuple group: two a tuple on average; more: the speculation is off
+constexpr uint32_t FJ_REC_CAP = 512;                  // records (second and later matches; 8 bytes each, room for 16) of one 256-tuple group: two a tuple on average; more: k_join_walk takes the unit
 // bytes of FusedArgs::ovf for `wgs` workgroups: two overflow buffers each, and behind them all a piece of FJ_REC_CAP records per wave
 // (fj_walk_group's staging)
 constexpr size_t fj_ovf_bytes(size_t wgs) { return wgs * 2 * (size_t)32768 * 8 + wgs * (size_t)(1024 / 64) * FJ_REC_CAP * 16; }
@@ -996,8 +996,9 @@ __device__ __forceinline__ void fj_emit_res(const FusedArgs &f, const IX &X, con
 // every step each lane takes the next candidate of the first of its four tuples that has one, so a step is ONE gather with most
 // lanes busy (a round per match ordinal was four gathers with a quarter, a twelfth, a fiftieth of the lanes: the vector memory
 // instructions a group issues, not their lanes, set this phase's pace — 70 a group with the overflow runs and the four-ordinal
-// emit loop, profiles/README.md r04b).  A second or later match leaves a 16-byte record {build row id, probe row id, tuple,
-// ordinal} in the wave's own piece of the overflow buffer (always the same 4 KB: L1/L2-resident); the matches of a tuple are
+// emit loop, profiles/README.md r04b).  A second or later match leaves an 8-byte record {build row id, tuple | ordinal}
+// in the wave's own piece of the overflow buffer (always the same 4 KB: L1/L2-resident; the probe row id stays in the lane that
+// holds the tuple and is shuffled to the record when it is read back: 16-byte records with it cost 2.5 % of the kernel); the matches of a tuple are
 // found in slot order = descending build position (rhjoin.c:219-250), so the ordinal is the number found before.  Then the
 // group's total goes into the chained scan of the unit's groups (fj_group_lookback), the first matches leave from the
 // registers and the records are read back 64 at a time, each pair to its tuple's offset + ordinal.  Returns the lane's matches.
@@ -1096,7 +1097,11 @@ __device__ __forceinline__ uint32_t fj_walk_group(const IX &X, const FjGather<N3
             const uint64_t mk = __ballot(isrec);
             const uint32_t slot = ne + (uint32_t)__popcll(mk & lt);
 #ifndef FJ_ABL_NOREC      // (timing experiment only, wrong results: second and later matches are found but leave no record and no pair)
+#ifndef FJ_REC16
+            if (isrec && slot < FJ_REC_CAP) reinterpret_cast<uint2 *>(rec)[slot] = make_uint2(g[j].z, (ks[j] * WAVE + lane) | (cc << 8));
+#else
             if (isrec && slot < FJ_REC_CAP) rec[slot] = make_uint4(g[j].z, pr[j], (ks[j] * WAVE + lane) | (cc << 8), 0u);
+#endif
 #endif
             ne += (uint32_t)__popcll(mk);
             cannot = cannot || (eq && cc >= 65535u);   // (the ordinal has sixteen bits)
@@ -1114,13 +1119,27 @@ __device__ __forceinline__ uint32_t fj_walk_group(const IX &X, const FjGather<N3
 
 // the records of a group, read back 64 at a time: each pair to its tuple's offset (off[k] of the lane that holds the tuple) + ordinal
 __device__ __forceinline__ void fj_emit_records(bool flip, const uint4 *rec, uint32_t nrec, const uint32_t (&off)[FJ_V], uint64_t wbase,
-                                                uint4 *out, uint64_t cap)
+                                                uint4 *out, uint64_t cap, const uint4 (&q)[FJ_V])
 {
     constexpr int V = FJ_V;
     const uint32_t lane = threadIdx.x & 63;
+    (void)q;
     for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
         const uint32_t e = e0 + lane;
+#ifndef FJ_REC16          // 8-byte records {build row id, tuple | ordinal}: the probe row id comes from the lane that holds the tuple (16-byte
+                         // records with the probe row id in them, -DFJ_REC16: C3 probe stage 1.837 -> 1.883 ms)
+        const uint2 r8 = e < nrec ? reinterpret_cast<const uint2 *>(rec)[e] : make_uint2(0, 0);
+        uint4 r = make_uint4(r8.x, 0u, r8.y, 0u);
+        {
+            const int s8 = (int)(r.z & 63u);
+            const uint32_t k8 = (r.z >> 6) & 3u;
+            r.y = __shfl(q[0].z, s8, 64);
+#pragma unroll
+            for (int k = 1; k < V; ++k) { const uint32_t pk = __shfl(q[k].z, s8, 64); if (k8 == (uint32_t)k) r.y = pk; }
+        }
+#else
         const uint4 r = e < nrec ? rec[e] : make_uint4(0, 0, 0, 0);
+#endif
         const int src = (int)(r.z & 63u);
         const uint32_t kk = (r.z >> 6) & 3u;
         uint32_t o = __shfl(off[0], src, 64);
@@ -1159,7 +1178,7 @@ __device__ __forceinline__ uint32_t fj_group_direct(const IX &X, const FjGather<
         const uint64_t at = wbase + off[k];
         if (c[k] != 0 && at < cap) FJ_STORE_PAIR(&out[at], make_pair(flip, q[k].z, 0u, first[k], 0u));
     }
-    fj_emit_records(flip, rec, nrec, off, wbase, out, cap);
+    fj_emit_records(flip, rec, nrec, off, wbase, out, cap, q);
     return cs;
 }
 
