@@ -163,7 +163,8 @@ template <bool N32> __device__ __forceinline__ uint4 pt_load_nt(const rhj_tuple 
     return pt_load<N32>(base, i);
 }
 #ifdef FJ_OUT_NT
-#define FJ_STORE_PAIR(ptr, v) do { const uint4 v_ = (v); uint32_t *p_ = reinterpret_cast<uint32_t *>(ptr); __builtin_nontemporal_store(v_.x, p_); __builtin_nontemporal_store(v_.y, p_ + 1); __builtin_nontemporal_store(v_.z, p_ + 2); __builtin_nontemporal_store(v_.w, p_ + 3); } while (0)
+typedef uint32_t fj_v4u __attribute__((ext_vector_type(4)));
+#define FJ_STORE_PAIR(ptr, v) do { const uint4 v_ = (v); const fj_v4u w_ = {v_.x, v_.y, v_.z, v_.w}; __builtin_nontemporal_store(w_, reinterpret_cast<fj_v4u *>(ptr)); } while (0)
 #else
 #define FJ_STORE_PAIR(ptr, v) (*(ptr) = (v))
 #endif
