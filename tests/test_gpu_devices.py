@@ -112,6 +112,21 @@ for bits in (4, 8, 11):
     # a list that does not fit its device's buffer: the count comes back, rc 1
     caps2 = (C.c_uint64 * n)(*[10] * n)
     assert lib.rhj_join_devices(pr, len(R), ps, len(S), po, caps2, ms) == 1 and sum(int(m) for m in ms) == len(want)
+# (6) a join on the reference's 4 bits whose buckets are beyond the fused kernels' index: every device's share runs the low-radix
+# path (its first pass drops the other devices' buckets), through the host entry point and through rhj_join_devices
+R4 = o.generate(1_200_000, 0, 0, 0.0, 21); S4 = o.generate(1_500_000, 1, 1_200_000, 0.0, 22)
+rhj.set_bits(4)
+want4 = o.join(R4, S4, 4)
+got4 = rhj.RadixHashJoin(R4, S4)
+assert len(got4) == len(want4) and (got4 == want4).all(), "RadixHashJoin on 4 bits"
+d4R, d4S = rhj.to_device(R4), rhj.to_device(S4)
+cap4 = len(want4) + 16
+out4 = [torch.empty((cap4, 2), dtype=torch.int64, device=rhj.dev) for _ in range(n)]
+p4r = (C.c_void_p * n)(*[d4R.data_ptr()] * n); p4s = (C.c_void_p * n)(*[d4S.data_ptr()] * n); p4o = (C.c_void_p * n)(*[t.data_ptr() for t in out4])
+caps4 = (C.c_uint64 * n)(*[cap4] * n); ms4 = (C.c_uint64 * n)()
+assert lib.rhj_join_devices(p4r, len(R4), p4s, len(S4), p4o, caps4, ms4) == 0
+assert (np.concatenate([rhj.pairs_to_numpy(t)[:int(m)] for t, m in zip(out4, ms4)]) == want4).all(), "rhj_join_devices on 4 bits"
+assert rhj.stats()["path"] == "lowradix", rhj.stats()
 lib.rhj_release()
 print("ok")
 '''
