@@ -248,8 +248,13 @@ constexpr uint32_t FJ_LONG = 16;                      // slots above this are fi
 // FJ_SMALL (FjIndexT::SMALL): batches of 4096 build tuples whose (slot, tag) words are kept in registers for the fill pass
 template <bool RES, bool N32, class IX>
 __device__ __forceinline__ void fj_build(const IX &X, const rhj_tuple *part, uint64_t boff, uint32_t bc, uint4 *ltup,
-                                         uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick)
+                                         uint32_t *tmp, uint32_t *wsum, uint32_t *sh_pick, bool any_order = false)
 {
+    // any_order (workgroup-uniform): the entries of a slot may stand in ANY order — every slot is filled by fetch-add and nothing
+    // is ranked.  For the units of the speculative gather kernel that the hypothesis' relation probes: a probe tuple there has one
+    // match or the speculation is off (and the ordinary kernel builds its own index), so the order the reference hands out a
+    // tuple's matches in (descending build position, rhjoin.c:219-250) never shows.  Ordered insertion is ~1.5 LDS atomics with a
+    // dependent loop per build tuple against one: C3 probe stage -0.7 % (timing-only on all units: 1.841 -> 1.814 ms).
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ndw = (X.hs + 3u) / 2u;
     for (uint32_t i = tid; i < ndw; i += FJ_BLOCK) X.dirw[i] = 0;
@@ -320,14 +325,14 @@ __device__ __forceinline__ void fj_build(const IX &X, const rhj_tuple *part, uin
     bool has_long = false;
     auto insert = [&](uint32_t sl, uint32_t v) {
         const uint32_t a = X.H(sl + 1u), n = X.H(sl + 2u) - a;
-        if (n <= FJ_LONG) {
+        if (!any_order && n <= FJ_LONG) {
             for (uint32_t p = a;; ++p) {
                 const uint32_t old = atomicMax(&X.ent[p], v);
                 if (old == 0) break;
                 v = min(old, v);
             }
         } else {
-            has_long = true;
+            has_long = !any_order;
             const uint32_t arrival = atomicAdd(&X.ent[a + n - 1u], 1u);
             X.ent[a + arrival] = v;                  // arrival n - 1: everybody has counted, the counter cell is free
         }
@@ -1298,7 +1303,7 @@ __device__ __forceinline__ void fj_body(const FusedArgs &f, uint32_t lds_bytes)
     if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 0] = __builtin_amdgcn_s_memrealtime();
     // ---- build
     if (RES) fj_build<true, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
-    else     fj_build<false, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick);
+    else     fj_build<false, N32>(X, bdp, bpos, bc, ltup, reinterpret_cast<uint32_t *>(O.buf), wsum, &sh_pick, SPEC && !MAYRES && fkp);
     if (FJ_ABLATE == 1) continue;                      // timing experiment: build only
     if (FJ_DBG && threadIdx.x == 0) FJ_DBG[(size_t)u * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
